@@ -1,0 +1,84 @@
+"""ctypes binding of the C ABI declared in include/graphik_amd.h.
+
+There is NO fallback: if the HIP library is missing or fails to load, importing the symbols
+raises.  (The CPU restatement under oracle/ is test infrastructure and is never used here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgraphik_amd.so")
+
+TERM_EQ, TERM_LOWER, TERM_UPPER = 1, 2, 3
+ABI_VERSION = 1
+
+
+class TemplateDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("N", C.c_int32), ("k", C.c_int32), ("n_terms", C.c_int32),
+        ("term_i", C.POINTER(C.c_int32)), ("term_j", C.POINTER(C.c_int32)),
+        ("term_kind", C.POINTER(C.c_int32)),
+        ("mingradnorm", C.c_double), ("maxiter", C.c_int32), ("maxinner", C.c_int32),
+        ("mininner", C.c_int32), ("theta", C.c_double), ("kappa", C.c_double),
+        ("rho_prime", C.c_double), ("rho_regularization", C.c_double),
+        ("planar_proj_exact", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [("f", C.c_double), ("gradnorm", C.c_double), ("iterations", C.c_int32),
+                ("inner_total", C.c_int32), ("stop", C.c_int32), ("n_accept", C.c_int32)]
+
+
+class Trace(C.Structure):
+    _fields_ = [("cap", C.c_int32), ("d_Delta", C.c_void_p), ("d_numit", C.c_void_p),
+                ("d_stop", C.c_void_p), ("d_f_before", C.c_void_p),
+                ("d_gradnorm_after", C.c_void_p), ("d_accept", C.c_void_p)]
+
+
+# every symbol include/graphik_amd.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "gik_last_error": (C.c_char_p, []),
+    "gik_abi_version": (C.c_int, []),
+    "gik_device_count": (C.c_int, []),
+    "gik_default_params": (None, [C.POINTER(TemplateDesc)]),
+    "gik_template_create": (C.c_int, [C.POINTER(TemplateDesc), C.POINTER(C.c_void_p)]),
+    "gik_template_destroy": (None, [C.c_void_p]),
+    "gik_cost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "gik_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "gik_hess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                           C.c_void_p]),
+    "gik_proj": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "gik_solve_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.POINTER(Trace), C.c_void_p]),
+}
+
+_lib = None
+
+
+class GikError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libgraphik_amd.so (raises if it has not been built: python -m graphik_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GikError(
+                f"HIP extension not built: {LIB_PATH} is missing. Run `python -m graphik_amd.build` "
+                "(or __graft_entry__.build()). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if L.gik_abi_version() != ABI_VERSION:
+            raise GikError("libgraphik_amd.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise GikError(lib().gik_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,518 @@
+// graphik_amd/csrc/gik_solve.hip -- kernels + C ABI (include/graphik_amd.h) for gfx950.
+//
+//   rtr_wave_kernel : whole Riemannian trust-region solve (TrustRegions.solve +
+//                     _truncated_conjugate_gradient, graphik/solvers/trust_region.py:112-599)
+//                     of one IK problem per wavefront, one launch per batch.
+//   kat_wave_kernel : the same device functions exposed one call at a time, batched
+//                     (costgrd twins + PSDFixedRank.proj) for known-answer parity tests.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "gik_wave.hip.h"
+#include "graphik_amd.h"
+
+namespace gik {
+
+// ------------------------------------------------------------------------------------------
+struct SolveArgs {
+  const uint32_t *slot_meta;  // [MAXDEG][64]
+  const double *targets;      // [B][T]
+  const double *Y_init;       // [B][N*K]
+  double *Y_out;              // [B][N*K]
+  gik_stats *stats;           // [B]
+  unsigned int *work_counter; // zeroed before launch; problems are claimed with atomicAdd
+  gik_trace trace;
+  int has_trace;
+  int N, T, B;
+  int dbg;  // debug flags (env GIK_DBG): 1 = one block per problem, 2 = skip the TR loop
+  Params p;
+};
+
+// Branch conditions on solver scalars are identical in all 64 lanes; routing them through a
+// ballot makes that explicit (the predicate lands in an SGPR pair, the branch is scalar) so the
+// structurizer never builds exec-masked loops around the wave-level reductions.
+#define UNI(cond) (__builtin_amdgcn_ballot_w64(cond) != 0ull)
+
+// Stage the launch-invariant slot table into LDS and zero the gather tiles (idle lanes and
+// padding slots read the never-written dump row, which must hold finite zeros).
+template <typename Ctx>
+__device__ inline void stage_lds(double *tiles, uint32_t *meta, const uint32_t *g_meta, int lane,
+                                 int maxdeg, int ktiles) {
+  for (int t = lane; t < ktiles * Ctx::TILE; t += WAVE) tiles[t] = 0.0;
+  for (int s = 0; s < maxdeg; ++s) meta[s * WAVE + lane] = g_meta[s * WAVE + lane];
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Persistent kernel: grid = (resident waves), each wavefront claims IK problems from a global
+// counter until the batch is exhausted.  Iteration counts differ by >50x between goals and the
+// hardware hands workgroups to XCDs round-robin, so a static block->problem map leaves whole
+// XCDs idle behind a few stragglers; the queue keeps every SIMD busy until the end.
+template <int K, int MAXDEG>
+__global__ void __launch_bounds__(WAVE) rtr_wave_kernel(SolveArgs a) {
+  using Ctx = WaveCtx<K, MAXDEG>;
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x;
+  const int NK = a.N * K;
+  double *sh_tiles = smem;
+  double *sh_tgt = smem + K * Ctx::TILE;
+  uint32_t *sh_meta = reinterpret_cast<uint32_t *>(sh_tgt + ((a.T + 1) & ~1));
+  stage_lds<Ctx>(sh_tiles, sh_meta, a.slot_meta, lane, MAXDEG, K);
+
+  Ctx cx;
+  cx.init(lane, a.N, sh_tiles, sh_tgt, sh_meta);
+  const Params &p = a.p;
+  const double Delta_bar = 10.0 + K;  // typicaldist (fixed_rank_psd_sym.py:71-73)
+
+  int pass = 0;
+  for (;;) {
+    int b = 0;
+    if (a.dbg & 1) {
+      b = (int)blockIdx.x + pass * (int)gridDim.x;
+      ++pass;
+    } else {
+      if (lane == 0) b = (int)atomicAdd(a.work_counter, 1u);
+      b = __builtin_amdgcn_readlane(b, 0);  // lane 0 explicitly, independent of exec
+    }
+    if (UNI(b >= a.B)) break;
+
+    for (int t = lane; t < a.T; t += WAVE) sh_tgt[t] = a.targets[(size_t)b * a.T + t];
+    __builtin_amdgcn_wave_barrier();
+    double x = cx.active ? a.Y_init[(size_t)b * NK + lane] : 0.0;
+
+    double Delta = Delta_bar / 8.0;         // trust_region.py:134-135,164
+    double fx = cx.cost(x);                 // :159
+    double g = cx.commit();                 // :160  (also loads the slot constants at x)
+    cx.proj_setup(p.planar_proj_exact);
+    double norm_grad = sqrt(wave_sum(g * g));  // :161
+    int kiter = 0, inner_total = 0, n_accept = 0, stop = 1;
+    bool bad = UNI(!(fx == fx) || !(norm_grad == norm_grad));
+    if (a.dbg & 2) bad = true;
+
+    while (!bad) {
+      // -------------- _truncated_conjugate_gradient (trust_region.py:436-599) -------------
+      double eta = 0.0, Heta = 0.0, r = g;       // :444-448
+      double e_Pe = 0.0;
+      double r_r = wave_sum(r * r);              // :455
+      const double norm_r0 = sqrt(r_r);
+      const double nr0_theta = (p.theta == 1.0) ? norm_r0 : pow(norm_r0, p.theta);
+      const double target = norm_r0 * fmin(nr0_theta, p.kappa);  // rhs of :572
+      const double target2 = target * target;
+      double z_r = r_r, d_Pd = r_r;              // :464-466 (precon = identity)
+      double delta = -r;                         // :469
+      double e_Pd = 0.0, model_value = 0.0;      // :471,485
+      int stop_tCG = TCG_MAX_INNER_ITER;         // :491
+      int j = 0;
+      for (j = 0; j < p.maxinner; ++j) {         // :495
+        double d_Hd;
+        const double Hdelta = cx.hess_proj_dot(delta, d_Hd);  // :497-500
+        if (UNI(!(d_Hd == d_Hd))) { bad = true; break; }
+        const double alpha = z_r / d_Hd;                  // :503
+        const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;  // :506
+        if (UNI(d_Hd <= 0.0 || e_Pe_new >= Delta * Delta)) {   // :509
+          const double tau =
+              (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta * Delta - e_Pe))) / d_Pd;  // :514
+          eta = eta + tau * delta;                        // :516
+          Heta = Heta + tau * Hdelta;                     // :521
+          stop_tCG = (d_Hd <= 0.0) ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;  // :531-534
+          break;
+        }
+        e_Pe = e_Pe_new;                                  // :537
+        const double new_eta = eta + alpha * delta;       // :538
+        const double new_Heta = Heta + alpha * Hdelta;    // :542
+        const double new_r = r + alpha * Hdelta;          // :561 (speculative; same value)
+        double m[3] = {new_eta * g, new_eta * new_Heta, new_r * new_r};
+        wave_sum_n<3>(m);
+        const double new_model_value = m[0] + 0.5 * m[1]; // :551
+        if (UNI(new_model_value >= model_value)) {        // :552
+          stop_tCG = TCG_MODEL_INCREASED;
+          break;
+        }
+        eta = new_eta;                                    // :556-558
+        Heta = new_Heta;
+        model_value = new_model_value;
+        r = new_r;                                        // :561
+        r_r = m[2];                                       // :564
+        // :572  norm_r <= norm_r0*min(norm_r0^theta, kappa), compared on the squares
+        if (UNI(j >= p.mininner && r_r <= target2)) {
+          stop_tCG = (p.kappa < nr0_theta) ? TCG_REACHED_TARGET_LINEAR
+                                           : TCG_REACHED_TARGET_SUPERLINEAR;
+          break;
+        }
+        const double zold_rold = z_r;                     // :587
+        z_r = r_r;                                        // :589
+        const double beta = z_r / zold_rold;              // :592
+        delta = -r + beta * delta;                        // :593
+        e_Pd = beta * (e_Pd + alpha * d_Pd);              // :596
+        d_Pd = z_r + beta * beta * d_Pd;                  // :597
+      }
+      if (bad) break;
+      if (j >= p.maxinner) j = p.maxinner - 1;  // Python leaves j at the last index
+      inner_total += j + 1;
+
+      // -------------- outer iteration (trust_region.py:248-422) ---------------------------
+      if (a.has_trace && kiter < a.trace.cap && lane == 0) {
+        const size_t q = (size_t)b * a.trace.cap + kiter;
+        a.trace.d_Delta[q] = Delta;
+        a.trace.d_numit[q] = j;
+        a.trace.d_stop[q] = stop_tCG;
+        a.trace.d_f_before[q] = fx;
+      }
+      const double x_prop = x + eta;                     // :248 retr
+      const double fx_prop = cx.cost(x_prop);            // :251
+      double rhonum = fx - fx_prop;                      // :255
+      double gd[2] = {g * eta, eta * Heta};
+      wave_sum_n<2>(gd);
+      double rhoden = -gd[0] - 0.5 * gd[1];              // :256
+      const double rho_reg =
+          fmax(1.0, fabs(fx)) * 2.220446049250313e-16 * p.rho_regularization;  // :287
+      rhonum += rho_reg;                                 // :288
+      rhoden += rho_reg;                                 // :289
+      const bool model_decreased = rhoden >= 0.0;        // :311
+      const double rho = rhonum / rhoden;                // :317
+      if (rho < 0.25 || !model_decreased || !(rho == rho)) {  // :336
+        Delta = Delta / 4.0;                             // :338
+      } else if (rho > 0.75 &&
+                 (stop_tCG == TCG_NEGATIVE_CURVATURE || stop_tCG == TCG_EXCEEDED_TR)) {
+        Delta = fmin(2.0 * Delta, Delta_bar);            // :357-361
+      }
+      int accept = 0;
+      if (UNI(model_decreased && rho > p.rho_prime)) {   // :382
+        accept = 1;
+        ++n_accept;
+        x = x_prop;                                      // :385
+        fx = fx_prop;                                    // :386
+        g = cx.commit();                                 // :387 (rows of x_prop are in LDS)
+        cx.proj_setup(p.planar_proj_exact);
+        norm_grad = sqrt(wave_sum(g * g));               // :388
+      }
+      if (a.has_trace && kiter < a.trace.cap && lane == 0) {
+        const size_t q = (size_t)b * a.trace.cap + kiter;
+        a.trace.d_gradnorm_after[q] = norm_grad;
+        a.trace.d_accept[q] = accept;
+      }
+      kiter = kiter + 1;                                 // :394
+      // :414-416 stopping criterion (pymanopt 0.2.5 order: maxiter before gradnorm; the
+      // wall-clock maxtime test is not reproduced -- it is non-deterministic)
+      if (kiter >= p.maxiter) { stop = 1; break; }
+      if (UNI(norm_grad < p.mingradnorm)) { stop = 0; break; }
+      if (UNI(!(norm_grad == norm_grad) || !(fx == fx))) { bad = true; break; }
+    }
+    if (bad) stop = 2;
+
+    if (cx.active) a.Y_out[(size_t)b * NK + lane] = x;
+    if (lane == 0) {
+      gik_stats s;
+      s.f = fx;
+      s.gradnorm = norm_grad;
+      s.iterations = kiter;
+      s.inner_total = inner_total;
+      s.stop = stop;
+      s.n_accept = n_accept;
+      a.stats[b] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+struct KatArgs {
+  const uint32_t *slot_meta;
+  const double *targets;  // [B][T] (unused for proj)
+  const double *Y;        // [B][N*K]
+  const double *W;        // [B][N*K] (hess, proj)
+  double *out;            // cost: [B]; others: [B][N*K]
+  int N, T, B, mode;      // 0 cost, 1 grad, 2 hess, 3 proj
+  int planar_proj_exact;
+};
+
+template <int K, int MAXDEG>
+__global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
+  using Ctx = WaveCtx<K, MAXDEG>;
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const int NK = a.N * K;
+  double *sh_tiles = smem;
+  double *sh_tgt = smem + K * Ctx::TILE;
+  uint32_t *sh_meta = reinterpret_cast<uint32_t *>(sh_tgt + ((a.T + 1) & ~1));
+  stage_lds<Ctx>(sh_tiles, sh_meta, a.slot_meta, lane, MAXDEG, K);
+  for (int t = lane; t < a.T; t += WAVE)
+    sh_tgt[t] = a.targets ? a.targets[(size_t)b * a.T + t] : 0.0;
+  __builtin_amdgcn_wave_barrier();
+  Ctx cx;
+  cx.init(lane, a.N, sh_tiles, sh_tgt, sh_meta);
+  const double y = cx.active ? a.Y[(size_t)b * NK + lane] : 0.0;
+  const double w = (a.W && cx.active) ? a.W[(size_t)b * NK + lane] : 0.0;
+  if (a.mode == 0) {
+    const double f = cx.cost(y);
+    if (lane == 0) a.out[b] = f;
+    return;
+  }
+  double res = 0.0;
+  if (a.mode == 1) {
+    cx.put(y);
+    res = cx.commit();
+  } else if (a.mode == 2) {
+    cx.put(y);
+    (void)cx.commit();
+    res = cx.ehess(w);
+  } else {
+    cx.put(y);
+    cx.proj_setup(a.planar_proj_exact);
+    res = cx.proj(w);
+  }
+  if (cx.active) a.out[(size_t)b * NK + lane] = res;
+}
+
+// ------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+static int fail(const std::string &m) {
+  g_err = m;
+  return -1;
+}
+#define HIP_OK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+  } while (0)
+
+typedef void (*solve_fn)(SolveArgs);
+typedef void (*kat_fn)(KatArgs);
+typedef size_t (*lds_fn)(int);
+
+template <int K, int D>
+static size_t lds_bytes_of(int T) {
+  return WaveCtx<K, D>::lds_bytes(T);
+}
+
+struct Variant {
+  int K, maxdeg;
+  solve_fn solve;
+  kat_fn kat;
+  lds_fn lds;
+};
+#define GIK_VARIANT(K, D) {K, D, rtr_wave_kernel<K, D>, kat_wave_kernel<K, D>, lds_bytes_of<K, D>}
+static const Variant kVariants[] = {GIK_VARIANT(3, 10), GIK_VARIANT(3, 20), GIK_VARIANT(2, 6),
+                                    GIK_VARIANT(2, 16), GIK_VARIANT(2, 31)};
+
+}  // namespace gik
+
+struct gik_template {
+  int N, K, T, maxdeg;
+  gik::Params p;
+  const gik::Variant *variant;
+  uint32_t *d_slot_meta;
+  unsigned int *d_counters;  // ring of work-queue heads, one per in-flight solve call
+  std::atomic<unsigned> next_counter;
+  int device;
+  int n_cu;
+  int waves_per_cu;  // resident solve wavefronts per CU (from the occupancy query)
+  size_t smem_bytes;
+};
+static constexpr int kCounterRing = 256;
+
+extern "C" {
+
+const char *gik_last_error(void) { return gik::g_err.c_str(); }
+int gik_abi_version(void) { return GIK_ABI_VERSION; }
+
+int gik_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void gik_default_params(gik_template_desc *d) {
+  d->abi_version = GIK_ABI_VERSION;
+  d->mingradnorm = 0.5 * 1e-9;  // riemannian_solver.py:45
+  d->maxiter = 3000;            // :47
+  d->maxinner = 10000;          // trust_region.py:118
+  d->mininner = 1;              // trust_region.py:116
+  d->theta = 1.0;               // riemannian_solver.py:48
+  d->kappa = 0.1;               // :49
+  d->rho_prime = 0.1;           // trust_region.py:90
+  d->rho_regularization = 1e3;  // trust_region.py:92
+  d->planar_proj_exact = 0;
+}
+
+int gik_template_create(const gik_template_desc *d, gik_template **out) {
+  using namespace gik;
+  if (!d || !out) return fail("null argument");
+  if (d->abi_version != GIK_ABI_VERSION) return fail("ABI version mismatch");
+  if (d->k != 2 && d->k != 3) return fail("k must be 2 or 3");
+  if (d->N < 2 || d->N * d->k > WAVE || d->N > 32)
+    return fail("wave-per-problem path needs N*k <= 64 (use the block path for larger graphs)");
+  if (d->n_terms < 1 || d->n_terms > 4095) return fail("n_terms out of range");
+  const int N = d->N, T = d->n_terms;
+  // per-node slot lists, in (neighbour, kind) order == the order the reference's edge loop
+  // (row-major upper-triangle index pairs) accumulates into each row
+  std::vector<std::vector<uint32_t>> slots(N);
+  struct Ent { int j, kind, term, owner; };
+  std::vector<std::vector<Ent>> ents(N);
+  for (int t = 0; t < T; ++t) {
+    const int i = d->term_i[t], j = d->term_j[t], kind = d->term_kind[t];
+    if (i < 0 || j < 0 || i >= N || j >= N || i == j) return fail("bad term indices");
+    if (kind < GIK_TERM_EQ || kind > GIK_TERM_UPPER) return fail("bad term kind");
+    ents[i].push_back({j, kind, t, i < j ? 1 : 0});
+    ents[j].push_back({i, kind, t, j < i ? 1 : 0});
+  }
+  int maxdeg = 0;
+  for (int i = 0; i < N; ++i) {
+    std::stable_sort(ents[i].begin(), ents[i].end(), [](const Ent &a, const Ent &b) {
+      return a.j != b.j ? a.j < b.j : a.kind < b.kind;
+    });
+    maxdeg = std::max(maxdeg, (int)ents[i].size());
+  }
+  const Variant *var = nullptr;
+  for (const Variant &v : kVariants)
+    if (v.K == d->k && v.maxdeg >= maxdeg && (!var || v.maxdeg < var->maxdeg)) var = &v;
+  if (!var) return fail("node degree exceeds the largest compiled slot count");
+  const int MD = var->maxdeg;
+  std::vector<uint32_t> meta((size_t)MD * WAVE, 0);
+  for (int lane = 0; lane < WAVE; ++lane) {
+    const bool active = lane < N * d->k;
+    const int node = active ? lane / d->k : 0;
+    const int comp = active ? lane % d->k : 0;
+    for (int s = 0; s < MD; ++s) {
+      // padding slot: this lane's own row (idle lanes: the all-zero dump row), kind none
+      uint32_t m = meta_pack(active ? node : TILE_ROWS - 1, 0, 0, 0);
+      if (active && s < (int)ents[node].size()) {
+        const Ent &e = ents[node][s];
+        m = meta_pack(e.j, e.term, e.kind, (comp == 0 && e.owner) ? 1 : 0);
+      }
+      meta[(size_t)s * WAVE + lane] = m;
+    }
+  }
+  gik_template *t = new gik_template();
+  t->N = N;
+  t->K = d->k;
+  t->T = T;
+  t->maxdeg = MD;
+  t->variant = var;
+  t->p.mingradnorm = d->mingradnorm;
+  t->p.theta = d->theta;
+  t->p.kappa = d->kappa;
+  t->p.rho_prime = d->rho_prime;
+  t->p.rho_regularization = d->rho_regularization;
+  t->p.maxiter = d->maxiter;
+  t->p.maxinner = d->maxinner;
+  t->p.mininner = d->mininner;
+  t->p.planar_proj_exact = d->planar_proj_exact;
+  t->d_slot_meta = nullptr;
+  t->d_counters = nullptr;
+  t->next_counter = 0;
+  t->smem_bytes = var->lds(T);
+  hipDeviceProp_t prop;
+  int occ = 0;
+  if (hipGetDevice(&t->device) != hipSuccess ||
+      hipGetDeviceProperties(&prop, t->device) != hipSuccess ||
+      hipMalloc((void **)&t->d_slot_meta, meta.size() * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc((void **)&t->d_counters, kCounterRing * sizeof(unsigned int)) != hipSuccess ||
+      hipMemcpy(t->d_slot_meta, meta.data(), meta.size() * sizeof(uint32_t),
+                hipMemcpyHostToDevice) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)var->solve, WAVE,
+                                                   t->smem_bytes) != hipSuccess) {
+    if (t->d_slot_meta) (void)hipFree(t->d_slot_meta);
+    if (t->d_counters) (void)hipFree(t->d_counters);
+    delete t;
+    return fail("HIP device setup failed (no GPU?)");
+  }
+  t->n_cu = prop.multiProcessorCount;
+  t->waves_per_cu = std::max(1, std::min(occ, 32));
+  *out = t;
+  return 0;
+}
+
+void gik_template_destroy(gik_template *t) {
+  if (!t) return;
+  if (t->d_slot_meta) (void)hipFree(t->d_slot_meta);
+  if (t->d_counters) (void)hipFree(t->d_counters);
+  delete t;
+}
+
+static int launch_kat(const gik_template *t, int mode, const double *d_Y, const double *d_W,
+                      const double *d_targets, int B, double *d_out, void *stream) {
+  using namespace gik;
+  if (!t || !d_Y || !d_out || B < 0) return fail("bad argument");
+  if (B == 0) return 0;
+  KatArgs a;
+  a.slot_meta = t->d_slot_meta;
+  a.targets = d_targets;
+  a.Y = d_Y;
+  a.W = d_W;
+  a.out = d_out;
+  a.N = t->N;
+  a.T = t->T;
+  a.B = B;
+  a.mode = mode;
+  a.planar_proj_exact = t->p.planar_proj_exact;
+  hipLaunchKernelGGL(t->variant->kat, dim3(B), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int gik_cost(const gik_template *t, const double *d_Y, const double *d_targets, int B,
+             double *d_f, void *stream) {
+  if (!d_targets) return gik::fail("targets required");
+  return launch_kat(t, 0, d_Y, nullptr, d_targets, B, d_f, stream);
+}
+int gik_grad(const gik_template *t, const double *d_Y, const double *d_targets, int B,
+             double *d_out, void *stream) {
+  if (!d_targets) return gik::fail("targets required");
+  return launch_kat(t, 1, d_Y, nullptr, d_targets, B, d_out, stream);
+}
+int gik_hess(const gik_template *t, const double *d_Y, const double *d_W,
+             const double *d_targets, int B, double *d_out, void *stream) {
+  if (!d_targets || !d_W) return gik::fail("targets and W required");
+  return launch_kat(t, 2, d_Y, d_W, d_targets, B, d_out, stream);
+}
+int gik_proj(const gik_template *t, const double *d_Y, const double *d_Z, int B, double *d_out,
+             void *stream) {
+  if (!d_Z) return gik::fail("Z required");
+  return launch_kat(t, 3, d_Y, d_Z, nullptr, B, d_out, stream);
+}
+
+int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double *d_targets,
+                    int B, double *d_Y_out, gik_stats *d_stats, const gik_trace *trace,
+                    void *stream) {
+  using namespace gik;
+  if (!t || !d_Y_init || !d_targets || !d_Y_out || !d_stats || B < 0) return fail("bad argument");
+  if (B == 0) return 0;
+  SolveArgs a;
+  a.slot_meta = t->d_slot_meta;
+  a.targets = d_targets;
+  a.Y_init = d_Y_init;
+  a.Y_out = d_Y_out;
+  a.stats = d_stats;
+  a.has_trace = (trace && trace->cap > 0) ? 1 : 0;
+  if (a.has_trace)
+    a.trace = *trace;
+  else
+    std::memset(&a.trace, 0, sizeof(a.trace));
+  a.N = t->N;
+  a.T = t->T;
+  a.B = B;
+  a.p = t->p;
+  {
+    const char *e = getenv("GIK_DBG");
+    a.dbg = e ? atoi(e) : 0;
+  }
+  gik_template *mt = const_cast<gik_template *>(t);  // the counter ring is the only mutable part
+  a.work_counter = t->d_counters + (mt->next_counter.fetch_add(1) % kCounterRing);
+  HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned int), (hipStream_t)stream));
+  const int grid = std::min(B, t->n_cu * t->waves_per_cu);
+  hipLaunchKernelGGL(t->variant->solve, dim3(grid), dim3(WAVE), t->smem_bytes,
+                     (hipStream_t)stream, a);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

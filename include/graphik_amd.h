@@ -1,0 +1,122 @@
+/*
+ * include/graphik_amd.h -- C ABI of the MI355X-native batched distance-geometric IK engine.
+ *
+ * This is the drop-in boundary for GraphIK's RiemannianSolver hot path.  The reference has no
+ * FFI of its own (it is pure Python); the interfaces these entry points replace are
+ *
+ *   (1) the numba-AOT extension `graphik.solvers.costgrd`
+ *       (graphik/solvers/costs.py:5-207, imported at graphik/solvers/riemannian_solver.py:18-21):
+ *           jcost/jgrad/jhess, lcost/lgrad/lhess            -> gik_cost / gik_grad / gik_hess
+ *   (2) the numba-jitted manifold methods
+ *       (graphik/utils/manifolds/fixed_rank_psd_sym.py:75-113): proj            -> gik_proj
+ *   (3) pymanopt-style `TrustRegions.solve(problem, x)` as called from
+ *       RiemannianSolver.solve (graphik/solvers/riemannian_solver.py:178-218,
+ *       graphik/solvers/trust_region.py:112-599)                         -> gik_solve_batch
+ *   (4) the per-goal pre/post-processing of solve_with_riemannian
+ *       (riemannian_solver.py:220-234; dgp.py:42-65,150-183,192-231;
+ *        graph_revolute.py:243-318, graph_planar.py:136-176)               -> gik_ik_batch
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  No torch / numpy types.
+ *   - All `d_*` pointers are DEVICE pointers (HBM) owned by the caller (e.g. the data_ptr() of
+ *     a PyTorch-ROCm tensor); the library never allocates inside a batch call except for the
+ *     handle's own persistent workspace, which grows monotonically with the largest B seen.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ *     asynchronous with respect to the host; synchronise the stream before reading results.
+ *   - Every function returns 0 on success, <0 on error; gik_last_error() returns a
+ *     thread-local message for the last failure.
+ *   - All floating point data is fp64 (IEEE double); vectors are N x k row-major like the
+ *     reference's numpy arrays.
+ */
+#ifndef GRAPHIK_AMD_H
+#define GRAPHIK_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GIK_ABI_VERSION 1
+
+/* Residual-term kinds: one "term" per (index pair, kind) exactly as the loops of
+ * costs.py:80-207 visit them: equality (omega != 0), lower hinge (psi_L != 0), upper hinge
+ * (psi_U != 0).                                                                           */
+enum { GIK_TERM_EQ = 1, GIK_TERM_LOWER = 2, GIK_TERM_UPPER = 3 };
+
+/* Problem-graph template: everything that does not depend on the goal pose.  Mirrors the
+ * arguments create_cost_limits() closes over (riemannian_solver.py:121-128): the index pairs
+ * `inds` (row-major upper triangle), and which of omega / psi_L / psi_U is set on each.   */
+typedef struct {
+  int32_t abi_version;   /* GIK_ABI_VERSION                                               */
+  int32_t N;             /* number of graph nodes (rows of Y)                             */
+  int32_t k;             /* embedding dimension: 3 (revolute) or 2 (planar)               */
+  int32_t n_terms;       /* number of residual terms T                                    */
+  const int32_t *term_i; /* [T] first node index  (i < j)                                 */
+  const int32_t *term_j; /* [T] second node index                                         */
+  const int32_t *term_kind; /* [T] GIK_TERM_*; terms sorted by (i, j, kind)               */
+  /* trust-region parameters (riemannian_solver.py:44-50, trust_region.py:85-121)          */
+  double mingradnorm;    /* 0.5e-9                                                        */
+  int32_t maxiter;       /* 3000                                                          */
+  int32_t maxinner;      /* 10000                                                         */
+  int32_t mininner;      /* 1                                                             */
+  double theta;          /* 1.0                                                           */
+  double kappa;          /* 0.1                                                           */
+  double rho_prime;      /* 0.1                                                           */
+  double rho_regularization; /* 1e3                                                       */
+  int32_t planar_proj_exact; /* 0: reproduce fixed_rank_psd_sym.py:107-110 literally (k=2) */
+} gik_template_desc;
+
+typedef struct gik_template gik_template; /* opaque handle, immutable after creation */
+
+/* Per-problem solver statistics (final_values of the reference's optlog + counters). */
+typedef struct {
+  double f;            /* final cost  f(x)                                                */
+  double gradnorm;     /* final ||grad||_F                                                */
+  int32_t iterations;  /* outer (trust-region) iterations                                 */
+  int32_t inner_total; /* Hessian-vector products (sum over tCG calls of numit+1)         */
+  int32_t stop;        /* 0: gradnorm < mingradnorm, 1: maxiter, 2: NaN encountered       */
+  int32_t n_accept;    /* accepted steps                                                  */
+} gik_stats;
+
+/* Optional per-outer-iteration trace (device arrays of B x cap; pass NULL to disable). */
+typedef struct {
+  int32_t cap;
+  double *d_Delta;
+  int32_t *d_numit;
+  int32_t *d_stop;
+  double *d_f_before;
+  double *d_gradnorm_after;
+  int32_t *d_accept;
+} gik_trace;
+
+const char *gik_last_error(void);
+int gik_abi_version(void);
+int gik_device_count(void);
+
+/* Set `desc->` trust-region fields to the reference defaults. */
+void gik_default_params(gik_template_desc *desc);
+
+int gik_template_create(const gik_template_desc *desc, gik_template **out);
+void gik_template_destroy(gik_template *t);
+
+/* costgrd twins, batched over B problems.  d_Y, d_W, d_out: [B][N*k]; d_targets: [B][T]
+ * (squared goal distance for EQ terms, psi_L / psi_U for hinge terms); d_f: [B].          */
+int gik_cost(const gik_template *t, const double *d_Y, const double *d_targets, int B,
+             double *d_f, void *stream);                      /* lcost / jcost            */
+int gik_grad(const gik_template *t, const double *d_Y, const double *d_targets, int B,
+             double *d_out, void *stream);                    /* lgrad / jgrad            */
+int gik_hess(const gik_template *t, const double *d_Y, const double *d_W,
+             const double *d_targets, int B, double *d_out, void *stream); /* lhess/jhess */
+int gik_proj(const gik_template *t, const double *d_Y, const double *d_Z, int B,
+             double *d_out, void *stream);                    /* PSDFixedRank.proj        */
+
+/* TrustRegions.solve for B problems: d_Y_init -> d_Y_out ([B][N*k]), d_stats [B].          */
+int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double *d_targets,
+                    int B, double *d_Y_out, gik_stats *d_stats, const gik_trace *trace,
+                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
