@@ -6,6 +6,11 @@ raises.  (The CPU restatement under oracle/ is test infrastructure and is never 
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own libamdhip64.so.7; it must be the HIP runtime this process uses (the
+# device pointers we are handed come from it).  Importing torch first makes the dynamic loader
+# resolve our library's libamdhip64.so.7 dependency to the copy torch already loaded.
+import torch  # noqa: F401  (ordering matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgraphik_amd.so")
 

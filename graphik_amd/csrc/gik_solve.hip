@@ -32,7 +32,9 @@ struct SolveArgs {
   gik_trace trace;
   int has_trace;
   int N, T, B;
-  int dbg;  // debug flags (env GIK_DBG): 1 = one block per problem, 2 = skip the TR loop
+  int dbg;  // debug flags (env GIK_DBG): 1 = one block per problem, 2 = skip the TR loop,
+            // 4 = dump (r_r, d_Hd, alpha, model) of every inner iteration of problem 0 to dbg_buf
+  double *dbg_buf;
   Params p;
 };
 
@@ -123,6 +125,10 @@ __global__ void __launch_bounds__(WAVE) rtr_wave_kernel(SolveArgs a) {
           Heta = Heta + tau * Hdelta;                     // :521
           stop_tCG = (d_Hd <= 0.0) ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;  // :531-534
           break;
+        }
+        if ((a.dbg & 4) && b == 0 && lane == 0 && a.dbg_buf && kiter < 64 && j < 128) {
+          double *q = a.dbg_buf + ((size_t)kiter * 128 + j) * 4;
+          q[0] = r_r; q[1] = d_Hd; q[2] = alpha; q[3] = model_value;
         }
         e_Pe = e_Pe_new;                                  // :537
         const double new_eta = eta + alpha * delta;       // :538
@@ -273,6 +279,7 @@ __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
 
 // ------------------------------------------------------------------------------------------
 thread_local std::string g_err;
+static double *g_dbg_buf = nullptr;
 static int fail(const std::string &m) {
   g_err = m;
   return -1;
@@ -441,8 +448,9 @@ void gik_template_destroy(gik_template *t) {
 static int launch_kat(const gik_template *t, int mode, const double *d_Y, const double *d_W,
                       const double *d_targets, int B, double *d_out, void *stream) {
   using namespace gik;
-  if (!t || !d_Y || !d_out || B < 0) return fail("bad argument");
+  if (!t || B < 0) return fail("bad argument");
   if (B == 0) return 0;
+  if (!d_Y || !d_out) return fail("null buffer");
   KatArgs a;
   a.slot_meta = t->d_slot_meta;
   a.targets = d_targets;
@@ -484,8 +492,9 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
                     int B, double *d_Y_out, gik_stats *d_stats, const gik_trace *trace,
                     void *stream) {
   using namespace gik;
-  if (!t || !d_Y_init || !d_targets || !d_Y_out || !d_stats || B < 0) return fail("bad argument");
+  if (!t || B < 0) return fail("bad argument");
   if (B == 0) return 0;
+  if (!d_Y_init || !d_targets || !d_Y_out || !d_stats) return fail("null buffer");
   SolveArgs a;
   a.slot_meta = t->d_slot_meta;
   a.targets = d_targets;
@@ -504,6 +513,14 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   {
     const char *e = getenv("GIK_DBG");
     a.dbg = e ? atoi(e) : 0;
+    a.dbg_buf = nullptr;
+    if (a.dbg & 4) {
+      static double *buf = nullptr;
+      if (!buf) (void)hipMalloc((void **)&buf, 64 * 128 * 4 * sizeof(double));
+      (void)hipMemset(buf, 0, 64 * 128 * 4 * sizeof(double));
+      a.dbg_buf = buf;
+      g_dbg_buf = buf;
+    }
   }
   gik_template *mt = const_cast<gik_template *>(t);  // the counter ring is the only mutable part
   a.work_counter = t->d_counters + (mt->next_counter.fetch_add(1) % kCounterRing);
@@ -513,6 +530,12 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
                      (hipStream_t)stream, a);
   HIP_OK(hipGetLastError());
   return 0;
+}
+
+// developer hook (not part of the ABI header): copy the GIK_DBG=4 dump to the host
+int gik_debug_fetch(double *host, int n) {
+  if (!gik::g_dbg_buf) return -1;
+  return hipMemcpy(host, gik::g_dbg_buf, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
 }  // extern "C"

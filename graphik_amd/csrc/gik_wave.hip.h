@@ -141,6 +141,9 @@ struct WaveCtx {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int t = 0; t < K; ++t) sh_tile[waddr[t]] = v;
+#ifdef GIK_LDS_WAIT
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+#endif
     __builtin_amdgcn_wave_barrier();
   }
 
@@ -348,31 +351,12 @@ struct WaveCtx {
     return out;
   }
 
-  // rhess(x, delta) = proj(ehess(delta)) together with <delta, rhess> (trust_region.py:497-500).
-  // One wave reduction serves both: vee(C) for the projection and the pieces of the curvature
-  //   <delta, H - Y Omega> = <delta, H> - sum_m o_m <delta, pk2_m>
-  // (identical quantity; only the order in which the inner product is summed differs).
+  // rhess(x, delta) = proj(ehess(delta)) and the curvature <delta, rhess> (trust_region.py
+  // :497-500), evaluated literally: project first, then reduce delta * Hdelta.
   __device__ inline double hess_proj_dot(double delta, double &d_Hd) {
-    const double H = ehess(delta);
-    double v[2 * NC + 1];
-#pragma unroll
-    for (int m = 0; m < NC; ++m) {
-      v[m] = pk[m] * H;
-      v[NC + 1 + m] = pk2[m] * delta;
-    }
-    v[NC] = delta * H;
-    wave_sum_n<2 * NC + 1>(v);
-    double out = H, dot = v[NC];
-#pragma unroll
-    for (int m = 0; m < NC; ++m) {
-      double o = 0.0;
-#pragma unroll
-      for (int q = 0; q < NC; ++q) o = fma(Pm[m * NC + q], v[q], o);
-      out = fma(-pk2[m], o, out);
-      dot = fma(-o, v[NC + 1 + m], dot);
-    }
-    d_Hd = dot;
-    return out;
+    const double Hd = proj(ehess(delta));
+    d_Hd = wave_sum(delta * Hd);
+    return Hd;
   }
 };
 

@@ -1,0 +1,264 @@
+"""Drop-in front end for GraphIK's Riemannian solver
+(graphik/solvers/riemannian_solver.py), running on the MI355X engine.
+
+    from graphik_amd.solvers.riemannian_solver import solve_with_riemannian, RiemannianSolver
+
+`solve_with_riemannian(graph, T_goal, use_jit=True)` and `RiemannianSolver(graph, params)
+.solve(D_goal, omega, use_limits, bounds, Y_init, jit, output_log)` keep the reference's
+signatures and return shapes; `jit` / `use_jit` are accepted and ignored (there is exactly one
+implementation: the HIP kernels -- no CPU fallback).  `solve_batch` is the batched entry point
+the engine is built for.
+"""
+import time
+
+import numpy as np
+import torch
+
+from ..engine import Template, build_terms
+from ..utils import dgp
+from ..utils.constants import POS
+from ..utils.lie import as_matrix
+
+_STOP_REASONS = {0: "Terminated - min grad norm reached", 1: "Terminated - max iterations reached",
+                 2: "Terminated - NaN encountered"}
+
+
+class RiemannianSolver:
+    def __init__(self, graph, params={}):
+        self.params = params
+        self.graph = graph
+        self.dim = graph.dim
+        self.N = graph.number_of_nodes()
+        solver_type = params.get("solver", "TrustRegions")
+        if solver_type == "ConjugateGradient":
+            raise NotImplementedError("only the TrustRegions solver is implemented on the GPU "
+                                      "(the reference's ConjugateGradient is pymanopt's)")
+        if solver_type != "TrustRegions":
+            raise ValueError("params[\"solver\"] must be one of 'ConjugateGradient', 'TrustRegions'")
+        # riemannian_solver.py:44-50
+        self.tr_params = {"mingradnorm": params.get("mingradnorm", 0.5 * 1e-9),
+                          "maxiter": int(params.get("maxiter", 3000)),
+                          "theta": params.get("theta", 1.0), "kappa": params.get("kappa", 0.1)}
+        for k in ("maxinner", "mininner", "rho_prime", "rho_regularization", "planar_proj_exact"):
+            if k in params:
+                self.tr_params[k] = params[k]
+        self.device = params.get("device", None)
+        self._templates = {}
+
+    # -- statics kept for API parity -----------------------------------------------------------
+    @staticmethod
+    def generate_initialization(bounds, dim, omega, psi_L=None, psi_U=None):
+        """riemannian_solver.py:67-75"""
+        return dgp.generate_initialization(bounds, dim, omega)
+
+    def _template(self, omega, psi_L, psi_U, use_limits):
+        key = (use_limits, omega.tobytes(), None if psi_L is None else psi_L.tobytes(),
+               None if psi_U is None else psi_U.tobytes())
+        if key not in self._templates:
+            self._templates[key] = Template.from_matrices(
+                omega, psi_L, psi_U, k=self.dim, use_limits=use_limits, device=self.device,
+                params=self.tr_params)
+        return self._templates[key]
+
+    def create_cost(self, D_goal, omega, jit=True):
+        """(cost, egrad, ehess) closures like riemannian_solver.py:77-119, evaluated on the GPU."""
+        return self._closures(D_goal, omega, None, None, False)
+
+    def create_cost_limits(self, D_goal, omega, psi_L, psi_U, jit=True):
+        """riemannian_solver.py:121-176"""
+        return self._closures(D_goal, omega, psi_L, psi_U, True)
+
+    def _closures(self, D_goal, omega, psi_L, psi_U, use_limits):
+        T = self._template(np.asarray(omega, dtype=float), psi_L, psi_U, use_limits)
+        tg = T.targets_from_D(D_goal)
+
+        def cost(Y):
+            return float(T.cost(Y, tg)[0])
+
+        def egrad(Y):
+            return T.grad(Y, tg)[0].cpu().numpy()
+
+        def ehess(Y, Z):
+            return T.hess(Y, Z, tg)[0].cpu().numpy()
+
+        return cost, egrad, ehess
+
+    # -- solve ----------------------------------------------------------------------------------
+    def solve(self, D_goal, omega, use_limits=False, bounds=None, Y_init=None, jit=True,
+              output_log=True):
+        """riemannian_solver.py:178-218.  D_goal / Y_init / bounds may carry a leading batch
+        axis; the return value is then a dict of arrays instead of a single final_values dict."""
+        omega = np.asarray(omega, dtype=float)
+        D_goal = np.asarray(D_goal, dtype=float)
+        batched = D_goal.ndim == 3
+        if use_limits:
+            psi_L, psi_U = self.graph.distance_bound_matrices()
+        else:
+            psi_L, psi_U = None, None
+        if bounds is not None:  # bounds take precedence over Y_init (:197-198)
+            lb, ub = np.asarray(bounds[0], dtype=float), np.asarray(bounds[1], dtype=float)
+            if lb.ndim == 2:
+                Y_init = dgp.generate_initialization((lb, ub), self.dim, omega)
+            else:
+                Y_init = dgp.generate_initialization_batch(lb, ub, self.dim, omega)
+        elif Y_init is None:
+            raise Exception("If not using bounds, provide an initialization!")
+        T = self._template(omega, psi_L, psi_U, use_limits)
+        t0 = time.time()
+        res = T.solve(Y_init, T.targets_from_D(D_goal))
+        torch.cuda.synchronize(T.device)
+        dt = time.time() - t0
+        x = res["x"].cpu().numpy()
+        B = x.shape[0]
+        info = {"x": x, "f(x)": res["f"].cpu().numpy(), "time": np.full(B, dt / B),
+                "gradnorm": res["gradnorm"].cpu().numpy(),
+                "iterations": res["iterations"].cpu().numpy(),
+                "inner_iterations": res["inner_total"].cpu().numpy(),
+                "stop": res["stop"].cpu().numpy()}
+        if not batched:
+            info = {k: (v[0] if k == "x" else v[0].item()) for k, v in info.items()}
+            info["stop_reason"] = _STOP_REASONS[int(info["stop"])]
+        return info if output_log else info["x"]
+
+
+# ---------------------------------------------------------------------------------------------
+class BatchProblem:
+    """Goal-independent data of solve_with_riemannian for one problem graph, prepared once:
+    edge template, which squared distances depend on the goal, anchors, limits."""
+
+    def __init__(self, graph, use_limits=True, params=None, device=None):
+        self.graph = graph
+        self.robot = graph.robot
+        self.dim = graph.dim
+        self.use_limits = use_limits
+        N = graph.number_of_nodes()
+        n = self.robot.n
+        ee = f"p{n}"
+        # goal nodes and how their positions follow from the goal pose (_pose_goal)
+        if self.dim == 3:
+            self.goal_nodes = [graph.index(ee), graph.index(f"q{n}")]
+        else:
+            self.goal_nodes = [graph.index(ee), graph.index(f"p{n - 1}")]
+        self.anchor_nodes = [i for i, name in enumerate(graph.node_ids)
+                             if POS in graph.nodes[name] and i not in self.goal_nodes]
+        self.anchor_pos = np.array([graph.nodes[graph.node_ids[i]][POS] for i in self.anchor_nodes],
+                                   dtype=float)
+        # a goal instance with a dummy pose gives the complete edge pattern (omega)
+        G0 = graph.from_pose(self.robot.pose(self.robot.zero_configuration(), ee))
+        self.omega = dgp.adjacency_matrix_from_graph(G0)
+        self.base_D = dgp.distance_matrix_from_graph(G0)
+        self.base_lower = np.where(G0.edge, G0.lower, np.nan)
+        self.base_upper = np.where(G0.edge, G0.upper, np.nan)
+        if use_limits:
+            self.psi_L, self.psi_U = graph.distance_bound_matrices()
+        else:
+            self.psi_L = self.psi_U = None
+        self.template = Template.from_matrices(self.omega, self.psi_L, self.psi_U, k=self.dim,
+                                               use_limits=use_limits, device=device, params=params)
+        self.N = N
+
+    def goal_positions(self, T_goals):
+        """[B,d+1,d+1] poses -> positions of the goal nodes [B,2,d]  (_pose_goal)."""
+        T = np.asarray(T_goals, dtype=float)
+        d = self.dim
+        if d == 3:
+            p = T[:, :3, 3]
+            q = p + T[:, :3, 2] * self.graph.axis_length
+            return np.stack((p, q), axis=1)
+        ee, pred = self.goal_nodes
+        dist = self.graph.dist[pred, ee]
+        p = T[:, :2, 2]
+        return np.stack((p, p - T[:, :2, 0] * dist), axis=1)
+
+    def assemble(self, T_goals):
+        """D_goal, LOWER, UPPER [B,N,N] for a batch of goals (from_pose + graph_complete_edges)."""
+        gp = self.goal_positions(T_goals)
+        B = gp.shape[0]
+        D = np.broadcast_to(self.base_D, (B, self.N, self.N)).copy()
+        lo = np.broadcast_to(self.base_lower, (B, self.N, self.N)).copy()
+        up = np.broadcast_to(self.base_upper, (B, self.N, self.N)).copy()
+        for gi, g in enumerate(self.goal_nodes):
+            dist = np.linalg.norm(gp[:, gi, None, :] - self.anchor_pos[None], axis=-1)  # [B,A]
+            for ai, a in enumerate(self.anchor_nodes):
+                D[:, a, g] = D[:, g, a] = dist[:, ai] ** 2
+                lo[:, a, g] = lo[:, g, a] = dist[:, ai]
+                up[:, a, g] = up[:, g, a] = dist[:, ai]
+        return D, lo, up
+
+    def prepare(self, T_goals, chunk=512):
+        """Host pre-processing for a batch: targets [B,T] and Y_init [B,N,k]."""
+        D, lo, up = self.assemble(T_goals)
+        Ys = []
+        for s in range(0, D.shape[0], chunk):
+            lb, ub = dgp.floyd_warshall_bounds(lo[s:s + chunk], up[s:s + chunk])
+            Ys.append(dgp.generate_initialization_batch(lb, ub, self.dim, self.omega))
+        return self.template.targets_from_D(D), np.concatenate(Ys, axis=0)
+
+    def joint_variables(self, Y, T_goals):
+        from ..graphs.graph_revolute import joint_variables_revolute_batch
+        from ..graphs.graph_planar import joint_variables_planar_batch
+        if self.dim == 3:
+            return joint_variables_revolute_batch(self.graph, Y, np.asarray(T_goals, dtype=float))
+        return joint_variables_planar_batch(self.graph, Y)
+
+    def pose_errors(self, q, T_goals):
+        """EE position / rotation error of FK(q) against the goals (the metric of
+        experiments/simple_ik_examples/test_chain_2d_new.py:62-66)."""
+        T_goals = np.asarray(T_goals, dtype=float)
+        T_sol = self.robot.fk_batch(q)
+        d = self.dim
+        pos = np.linalg.norm(T_goals[:, :d, d] - T_sol[:, :d, d], axis=1)
+        Rrel = T_goals[:, :d, :d] @ np.swapaxes(T_sol[:, :d, :d], 1, 2)
+        if d == 3:
+            c = np.clip(0.5 * np.trace(Rrel, axis1=1, axis2=2) - 0.5, -1.0, 1.0)
+            rot = np.arccos(c)
+        else:
+            rot = np.abs(np.arctan2(Rrel[:, 1, 0], Rrel[:, 0, 0]))
+        return pos, rot
+
+
+_PROBLEM_CACHE = {}
+
+
+def _problem_for(graph, use_limits=True, params=None, device=None):
+    key = (id(graph), graph.number_of_nodes(), use_limits, None if not params else tuple(sorted(params.items())),
+           device)
+    if key not in _PROBLEM_CACHE:
+        _PROBLEM_CACHE[key] = BatchProblem(graph, use_limits, params, device)
+    return _PROBLEM_CACHE[key]
+
+
+def solve_batch(graph, T_goals, use_limits=True, params=None, device=None, Y_init=None):
+    """Batched solve_with_riemannian.  T_goals: [B,d+1,d+1] array or list of poses.
+    Returns (q [B,n], Y [B,N,k], info dict of arrays)."""
+    T = np.stack([as_matrix(t) for t in T_goals]) if not isinstance(T_goals, np.ndarray) \
+        else np.asarray(T_goals, dtype=float)
+    prob = _problem_for(graph, use_limits, params, device)
+    targets, Y0 = prob.prepare(T)
+    if Y_init is not None:
+        Y0 = np.asarray(Y_init, dtype=float)
+    t0 = time.time()
+    res = prob.template.solve(Y0, targets)
+    torch.cuda.synchronize(prob.template.device)
+    dt = time.time() - t0
+    Y = res["x"].cpu().numpy()
+    q = prob.joint_variables(Y, T)
+    pos, rot = prob.pose_errors(q, T)
+    info = {"x": Y, "f(x)": res["f"].cpu().numpy(), "gradnorm": res["gradnorm"].cpu().numpy(),
+            "iterations": res["iterations"].cpu().numpy(),
+            "inner_iterations": res["inner_total"].cpu().numpy(),
+            "stop": res["stop"].cpu().numpy(), "time": np.full(len(Y), dt / max(len(Y), 1)),
+            "solve_time": dt, "pos_err": pos, "rot_err": rot}
+    return q, Y, info
+
+
+def solve_with_riemannian(graph, T_goal, use_jit=True, jit=None):
+    """riemannian_solver.py:220-234 on the GPU engine (B = 1).  `jit=` is accepted as an alias of
+    `use_jit=` because the reference's README spells it that way (README.md:45)."""
+    T = as_matrix(T_goal)[None]
+    q, Y, info = solve_batch(graph, T)
+    q_sol = graph.robot.array_to_q(q[0])
+    broken = graph.check_distance_limits(graph.realization(q_sol), tol=1e-6)
+    if len(broken) > 0:
+        return None, None
+    return q_sol, Y[0]

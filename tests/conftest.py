@@ -1,0 +1,67 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+SCENARIOS_3D = ["lwa4d", "ur10", "kuka"]
+SCENARIOS_2D = ["planar10_nolimits", "planar10_limits_pi", "planar10_limits_halfpi"]
+SCENARIOS = SCENARIOS_3D + SCENARIOS_2D
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = load_golden(name)
+        return cache[name]
+
+    return get
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
+
+
+def make_graph(name):
+    """(robot, graph) for a golden scenario, built with graphik_amd's own host layer."""
+    from graphik_amd.utils.roboturdf import load_schunk_lwa4d, load_ur10, load_kuka
+    from graphik_amd.robots import RobotPlanar
+    from graphik_amd.graphs import ProblemGraphPlanar
+    from graphik_amd.utils import list_to_variable_dict, table_environment
+    if name == "lwa4d":
+        return load_schunk_lwa4d()
+    if name == "ur10":
+        return load_ur10()
+    if name == "kuka":
+        return load_kuka()
+    if name == "ur10_table":
+        robot, graph = load_ur10()
+        for idx, obs in enumerate(table_environment()):
+            graph.add_spherical_obstacle(f"o{idx}", obs[0], obs[1])
+        return robot, graph
+    if name.startswith("planar10"):
+        n = 10
+        lim = np.array(9 * [np.pi / 2] + [np.pi]) if name.endswith("halfpi") else np.pi * np.ones(n)
+        robot = RobotPlanar({"link_lengths": list_to_variable_dict(np.ones(n)),
+                             "theta": list_to_variable_dict(np.zeros(n)),
+                             "joint_limits_upper": list_to_variable_dict(lim),
+                             "joint_limits_lower": list_to_variable_dict(-lim), "num_joints": n})
+        return robot, ProblemGraphPlanar(robot)
+    raise KeyError(name)

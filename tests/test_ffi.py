@@ -1,0 +1,54 @@
+"""The C-ABI library builds for gfx950, loads, and exports every symbol include/graphik_amd.h
+declares.  No compute (no GPU needed)."""
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def test_header_symbols_are_bound_and_exported():
+    from graphik_amd import _ffi, build
+    build.build()
+    hdr = open(os.path.join(REPO, "include", "graphik_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gik_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_ffi.SYMBOLS), declared ^ set(_ffi.SYMBOLS)
+    L = _ffi.lib()
+    for name in declared:
+        assert hasattr(L, name)
+    assert L.gik_abi_version() == _ffi.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from graphik_amd import _ffi
+    assert C.sizeof(_ffi.Stats) == 32
+    assert C.sizeof(_ffi.Trace) == 8 + 6 * 8
+    assert _ffi.TemplateDesc.N.offset == 4 and _ffi.TemplateDesc.term_i.offset == 16
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Creating an engine object without a HIP device must fail loudly."""
+    import torch
+    from graphik_amd import _ffi
+    from graphik_amd.engine import Template
+    import numpy as np
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    om = np.zeros((4, 4))
+    om[0, 1] = om[1, 0] = 1
+    with pytest.raises(_ffi.GikError):
+        Template.from_matrices(om, k=3, use_limits=False)
+
+
+def test_product_does_not_import_oracle():
+    """Nothing under graphik_amd/ may reference the CPU oracle."""
+    pkg = os.path.join(REPO, "graphik_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and \
+                    "gik_oracle" not in txt, f

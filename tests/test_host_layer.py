@@ -1,0 +1,173 @@
+"""Host-side mirror of the reference API (graphs, robots, dgp, loaders) against golden data
+captured from the reference, plus the reference's own round-trip properties
+(tests/test_joint_variables.py, test_bound_smoothing.py, test_distance_matrix.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENARIOS, SCENARIOS_3D, load_golden, make_graph
+from graphik_amd.utils import dgp
+from graphik_amd.utils.lie import SE2, SE3
+from graphik_amd.utils.utils import table_environment
+
+
+def _same(a, b, tol=0.0):
+    return np.array_equal(np.isnan(a), np.isnan(b)) and \
+        np.nanmax(np.abs(np.nan_to_num(a) - np.nan_to_num(b))) <= tol
+
+
+@pytest.mark.parametrize("name", SCENARIOS + ["ur10_table"])
+def test_template_matches_reference(name):
+    d = load_golden(name)
+    robot, graph = make_graph(name)
+    assert graph.node_ids == list(d["node_ids"])
+    assert _same(graph.dist, d["G_dist"]) and _same(graph.lower, d["G_lower"])
+    assert _same(graph.upper, d["G_upper"])
+    assert np.array_equal(np.where(graph.bounded == 5, 0, graph.bounded), d["G_bounded"])
+    L, U = graph.distance_bound_matrices()
+    assert np.array_equal(L, d["psi_L"]) and np.array_equal(U, d["psi_U"])
+    assert np.abs(robot.T0_array() - d["T0"]).max() == 0.0
+
+
+@pytest.mark.parametrize("name", SCENARIOS + ["ur10_table"])
+def test_goal_assembly_bounds_init(name):
+    d = load_golden(name)
+    robot, graph = make_graph(name)
+    SE = SE3 if graph.dim == 3 else SE2
+    for g in range(min(3, len(d["seed"]))):
+        G = graph.from_pose(SE.from_matrix(d["T_goal"][g]))
+        assert np.abs(dgp.distance_matrix_from_graph(G) - d["D_goal"][g]).max() < 1e-14 * max(1.0, np.abs(d["D_goal"][g]).max())
+        om = dgp.adjacency_matrix_from_graph(G)
+        assert np.array_equal(om, d["omega"])
+        lb, ub = dgp.bound_smoothing(G)
+        assert np.abs(lb - d["lb"][g]).max() < 1e-12 and np.abs(ub - d["ub"][g]).max() < 1e-12
+        Y0 = dgp.generate_initialization((lb, ub), graph.dim, om)
+        # eigenvector signs are free: compare up to per-column sign
+        assert np.abs(np.abs(Y0) - np.abs(d["Y_init"][g])).max() < 1e-9
+        assert np.abs(Y0 @ Y0.T - d["Y_init"][g] @ d["Y_init"][g].T).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_batched_preprocessing_equals_single(name):
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    d = load_golden(name)
+    robot, graph = make_graph(name)
+    use_lim = bool(int(d["use_limits"]))
+    prob = BatchProblem.__new__(BatchProblem)  # host part only: skip the device template
+    prob.graph, prob.robot, prob.dim, prob.use_limits = graph, robot, graph.dim, use_lim
+    n = robot.n
+    prob.goal_nodes = [graph.index(f"p{n}"), graph.index(f"q{n}" if graph.dim == 3 else f"p{n-1}")]
+    from graphik_amd.utils.constants import POS
+    prob.anchor_nodes = [i for i, nm in enumerate(graph.node_ids)
+                         if POS in graph.nodes[nm] and i not in prob.goal_nodes]
+    prob.anchor_pos = np.array([graph.nodes[graph.node_ids[i]][POS] for i in prob.anchor_nodes])
+    G0 = graph.from_pose(robot.pose(robot.zero_configuration(), f"p{n}"))
+    prob.omega = dgp.adjacency_matrix_from_graph(G0)
+    prob.base_D = dgp.distance_matrix_from_graph(G0)
+    prob.base_lower = np.where(G0.edge, G0.lower, np.nan)
+    prob.base_upper = np.where(G0.edge, G0.upper, np.nan)
+    prob.N = graph.number_of_nodes()
+    D, lo, up = prob.assemble(d["T_goal"])
+    assert np.array_equal(prob.omega, d["omega"])
+    assert np.abs(D - d["D_goal"]).max() < 1e-14 * max(1.0, np.abs(d["D_goal"]).max())
+    lb, ub = dgp.floyd_warshall_bounds(lo, up)
+    assert np.abs(lb - d["lb"]).max() < 1e-12 and np.abs(ub - d["ub"]).max() < 1e-12
+    Y0 = dgp.generate_initialization_batch(lb, ub, graph.dim, prob.omega)
+    assert np.abs(np.abs(Y0) - np.abs(d["Y_init"])).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_joint_variables_and_pose_errors_match_reference(name):
+    d = load_golden(name)
+    robot, graph = make_graph(name)
+    SE = SE3 if graph.dim == 3 else SE2
+    for g in range(len(d["seed"])):
+        T = SE.from_matrix(d["T_goal"][g])
+        q = graph.joint_variables(d["Y_sol"][g], {f"p{robot.n}": T})
+        assert np.abs(robot.q_to_array(q) - d["q_sol"][g]).max() < 1e-9
+        Ts = robot.pose(q, f"p{robot.n}")
+        assert abs(np.linalg.norm(T.trans - Ts.trans) - d["pos_err"][g]) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["lwa4d", "ur10", "kuka", "planar10"])
+def test_fk_realization_roundtrip(name):
+    """FK -> realization -> joint_variables recovers q (reference tests/test_joint_variables.py
+    :55-78), and FK / realization equal the reference's numbers."""
+    h = load_golden("host_kats")
+    robot, graph = make_graph("planar10_nolimits" if name == "planar10" else name)
+    Q = h[f"{name}_fk_q"]
+    for b in range(len(Q)):
+        q = robot.array_to_q(Q[b])
+        for i in range(1, robot.n + 1):
+            assert np.abs(robot.pose(q, f"p{i}").as_matrix() - h[f"{name}_fk_T"][b, i - 1]).max() < 1e-12
+        G = graph.realization(q)
+        assert np.abs(G.positions() - h[f"{name}_realization"][b]).max() < 1e-12
+        qr = graph.joint_variables(G, {f"p{robot.n}": robot.pose(q, f"p{robot.n}")})
+        assert np.abs(robot.q_to_array(qr) - h[f"{name}_jointvars"][b]).max() < 1e-9
+        assert np.abs(np.mod(robot.q_to_array(qr) - Q[b] + np.pi, 2 * np.pi) - np.pi).max() < 1e-6
+    assert np.abs(robot.fk_batch(Q) - h[f"{name}_fk_T"][:, robot.n - 1]).max() < 1e-12
+
+
+def test_bound_smoothing_brackets_true_distances():
+    """lb^2 - tol <= D_true <= ub^2 + tol (reference tests/test_bound_smoothing.py:99-117)."""
+    robot, graph = make_graph("ur10")
+    rng = np.random.RandomState(3)
+    for _ in range(5):
+        q = robot.array_to_q(rng.uniform(-np.pi, np.pi, robot.n))
+        T = robot.pose(q, f"p{robot.n}")
+        lb, ub = dgp.bound_smoothing(graph.from_pose(T))
+        D = dgp.distance_matrix_from_pos(graph.realization(q).positions())
+        assert np.all(lb ** 2 - 1e-8 <= D) and np.all(D <= ub ** 2 + 1e-8)
+
+
+def test_table_environment_and_obstacles():
+    h = load_golden("host_kats")
+    obs = table_environment()
+    assert np.array_equal(np.array([o[0] for o in obs]), h["table_centers"])
+    assert np.array_equal(np.array([o[1] for o in obs]), h["table_radii"])
+    robot, graph = make_graph("ur10_table")
+    assert graph.number_of_nodes() == 116
+    # reference quirk: no robot<->obstacle lower-bound edges, limit check inert
+    L, U = graph.distance_bound_matrices()
+    assert not np.any(L[16:, :16]) and graph.check_distance_limits(graph.realization(
+        robot.zero_configuration())) == []
+    graph.clear_obstacles()
+    assert graph.number_of_nodes() == 16
+
+
+def test_api_surface():
+    """Names and call shapes the reference's callers rely on."""
+    import graphik_amd.solvers.riemannian_solver as rs
+    import inspect
+    sig = inspect.signature(rs.solve_with_riemannian)
+    assert list(sig.parameters)[:3] == ["graph", "T_goal", "use_jit"] and "jit" in sig.parameters
+    sig = inspect.signature(rs.RiemannianSolver.solve)
+    assert list(sig.parameters) == ["self", "D_goal", "omega", "use_limits", "bounds", "Y_init",
+                                    "jit", "output_log"]
+    robot, graph = make_graph("lwa4d")
+    for attr in ("from_pose", "node_ids", "robot", "dim", "axis_length", "number_of_nodes",
+                 "distance_bound_matrices", "joint_variables", "realization",
+                 "check_distance_limits", "add_spherical_obstacle", "clear_obstacles"):
+        assert hasattr(graph, attr)
+    for attr in ("n", "dim", "random_configuration", "pose", "end_effectors", "lb", "ub"):
+        assert hasattr(robot, attr)
+    np.random.seed(0)
+    q = robot.random_configuration()
+    np.random.seed(0)
+    u = np.random.rand(robot.n)
+    assert np.allclose(robot.q_to_array(q), -np.pi + 2 * np.pi * u)  # robot_base.py:76-85
+    with pytest.raises(Exception):
+        rs.RiemannianSolver(graph, {"solver": "nope"})
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/graphik/robots/urdfs"),
+                    reason="reference URDF data only exists in the build container")
+@pytest.mark.parametrize("name,urdf", [("lwa4d", "lwa4d.urdf"), ("ur10", "ur10_mod.urdf"),
+                                       ("kuka", "kuka_iiwr.urdf")])
+def test_urdf_reader_reproduces_packaged_constants(name, urdf):
+    from graphik_amd.utils.roboturdf import RobotURDF
+    u = RobotURDF("/root/reference/graphik/robots/urdfs/" + urdf)
+    n = u.n_q_joints
+    r = u.make_Revolute3d(np.pi * np.ones(n), -np.pi * np.ones(n))
+    assert np.abs(r.T0_array() - load_golden(name)["T0"]).max() < 1e-12
