@@ -41,6 +41,21 @@ class Trace(C.Structure):
                 ("d_gradnorm_after", C.c_void_p), ("d_accept", C.c_void_p)]
 
 
+class PipelineDesc(C.Structure):
+    _fields_ = [
+        ("n_joints", C.c_int32), ("T0", C.POINTER(C.c_double)),
+        ("p_index", C.POINTER(C.c_int32)), ("q_index", C.POINTER(C.c_int32)),
+        ("x_index", C.c_int32), ("y_index", C.c_int32), ("axis_length", C.c_double),
+        ("goal_node0", C.c_int32), ("goal_node1", C.c_int32), ("goal_len", C.c_double),
+        ("base_lower", C.POINTER(C.c_double)), ("base_upper", C.POINTER(C.c_double)),
+        ("n_anchor", C.c_int32), ("anchor_index", C.POINTER(C.c_int32)),
+        ("anchor_pos", C.POINTER(C.c_double)),
+        ("n_pairs", C.c_int32), ("pair_i", C.POINTER(C.c_int32)), ("pair_j", C.POINTER(C.c_int32)),
+        ("term_src", C.POINTER(C.c_int32)), ("term_static", C.POINTER(C.c_double)),
+        ("last_link_along_z", C.c_int32), ("jacobi_sweeps", C.c_int32),
+    ]
+
+
 # every symbol include/graphik_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "gik_last_error": (C.c_char_p, []),
@@ -56,6 +71,13 @@ SYMBOLS = {
     "gik_proj": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gik_solve_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p, C.POINTER(Trace), C.c_void_p]),
+    "gik_pipeline_attach": (C.c_int, [C.c_void_p, C.POINTER(PipelineDesc)]),
+    "gik_prepare_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "gik_recover_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gik_ik_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

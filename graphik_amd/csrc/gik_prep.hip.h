@@ -1,0 +1,500 @@
+// graphik_amd/csrc/gik_prep.hip.h -- per-goal pre- and post-processing on the device.
+//
+//   prep_wave_kernel : one wavefront per goal, everything in LDS:
+//       goal pose -> anchor/goal distances (ProblemGraph.from_pose + graph_complete_edges,
+//       graph_base.py:146-180, dgp.py:124-147) -> bound smoothing (dgp.py:192-231)
+//       -> RiemannianSolver.generate_initialization (riemannian_solver.py:67-75: Gram of the
+//       0.9-interpolated bounds, MDS with the reference's rank rule, linear projection)
+//       -> per-term targets + Y_init for the solve kernel.
+//     The three symmetric eigendecompositions (N x N Gram, the N x N "rank" matrix, K x K
+//     scatter) are cyclic Jacobi sweeps in round-robin order: the N/2 rotations of a round act on
+//     disjoint index pairs, so a round is three conflict-free passes over LDS rows/columns.
+//   recover_kernel   : one thread per goal: joint_variables (graph_revolute.py:251-318 /
+//       graph_planar.py:147-176) + forward kinematics of the recovered angles -> EE pose error.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gik_wave.hip.h"
+
+namespace gik {
+
+struct PipeConst {
+  // graph template (device pointers)
+  const double *base_lower;   // [N*N]  NaN = no edge; goal edges are added per problem
+  const double *base_upper;   // [N*N]
+  const int *anchor_idx;      // [A]   nodes with a fixed position (base frame, obstacles)
+  const double *anchor_pos;   // [A][K]
+  const int *pair_i, *pair_j; // [P]   omega pairs (i<j), goal edges included
+  const int *term_src;        // [T]   -1: static target, else anchor_slot*2 + goal_slot
+  const double *term_static;  // [T]
+  // robot
+  const double *T0;           // [n+1][(K+1)^2] frames at zero configuration (row-major)
+  const int *p_idx, *q_idx;   // [n+1] node index of p_i / q_i
+  int N, K, T, n_anchor, n_pairs, n_joints;
+  int goal0, goal1;           // ee node, and q_n (k=3) or p_{n-1} (k=2)
+  int x_idx, y_idx;
+  double goal_len;            // axis_length (k=3) / |p_{n-1} p_n| (k=2)
+  double axis_length;
+  int last_along_z;           // joint_variables: last link offset parallel to z (:314)
+};
+
+// round-robin (chess tournament) pairing: n_even players, round r, table m
+__device__ inline void rr_pair(int n_even, int r, int m, int &p, int &q) {
+  if (m == 0) {
+    p = n_even - 1;
+    q = r;
+  } else {
+    p = (r + m) % (n_even - 1);
+    q = (r - m + n_even - 1) % (n_even - 1);
+  }
+  if (p > q) {
+    const int t = p;
+    p = q;
+    q = t;
+  }
+}
+
+// Cyclic Jacobi on the symmetric N x N matrix A (LDS, row stride N); V (optional) accumulates
+// the eigenvectors as columns.  cs: 2*16 doubles, pq: 16 ints of LDS scratch.
+__device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, double *cs, int *pq,
+                                  int lane) {
+  const int ne = N + (N & 1), np = ne / 2;
+  for (int sw = 0; sw < sweeps; ++sw) {
+    for (int r = 0; r < ne - 1; ++r) {
+      if (lane < np) {
+        int p, q;
+        rr_pair(ne, r, lane, p, q);
+        double c = 1.0, s = 0.0;
+        int code = -1;
+        if (q < N) {
+          const double apq = A[p * N + q];
+          if (fabs(apq) > 1e-300) {
+            const double th = (A[q * N + q] - A[p * N + p]) / (2.0 * apq);
+            const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+            c = 1.0 / sqrt(t * t + 1.0);
+            s = t * c;
+            code = p | (q << 8);
+          }
+        }
+        cs[2 * lane] = c;
+        cs[2 * lane + 1] = s;
+        pq[lane] = code;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // column phase: lanes [0,N) rotate A's columns (row = lane), lanes [32,32+N) rotate V's
+      for (int m = 0; m < np; ++m) {
+        const int code = pq[m];
+        if (code < 0) continue;
+        const int p = code & 0xff, q = code >> 8;
+        const double c = cs[2 * m], s = cs[2 * m + 1];
+        double *M = (lane < 32) ? A : V;
+        const int row = lane & 31;
+        if (row < N && M != nullptr) {
+          const double ap = M[row * N + p], aq = M[row * N + q];
+          M[row * N + p] = c * ap - s * aq;
+          M[row * N + q] = s * ap + c * aq;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // row phase on A (column = lane)
+      for (int m = 0; m < np; ++m) {
+        const int code = pq[m];
+        if (code < 0) continue;
+        const int p = code & 0xff, q = code >> 8;
+        const double c = cs[2 * m], s = cs[2 * m + 1];
+        if (lane < N) {
+          const double ap = A[p * N + lane], aq = A[q * N + lane];
+          A[p * N + lane] = c * ap - s * aq;
+          A[q * N + lane] = s * ap + c * aq;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// rank of eigenvalue c in DESCENDING order (ties broken by index), for lanes c < N
+__device__ inline int desc_rank(const double *ev, int N, int c) {
+  int rk = 0;
+  const double v = ev[c];
+  for (int j = 0; j < N; ++j) rk += (ev[j] > v) || (ev[j] == v && j < c);
+  return rk;
+}
+
+struct PrepArgs {
+  PipeConst pc;
+  const double *T_goal;  // [B][(K+1)^2]
+  double *targets;       // [B][T]
+  double *Y_init;        // [B][N*K]
+  int *K_out;            // [B] MDS column count (diagnostic), may be null
+  int B, sweeps;
+};
+
+__global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
+  extern __shared__ double smem[];
+  const PipeConst &pc = a.pc;
+  const int N = pc.N, K = pc.K, NN = N * N, lane = threadIdx.x;
+  double *U = smem;            // upper bounds -> ub
+  double *L = U + NN;          // lower bounds
+  double *A = L + NN;          // work matrix
+  double *V = A + NN;          // eigenvectors / temp
+  double *X = V + NN;          // MDS factor
+  double *gd = X + NN;         // [2*n_anchor] anchor<->goal distances
+  double *cs = gd + 2 * pc.n_anchor + (pc.n_anchor & 1) * 0;
+  double *ev = cs + 32;        // [32] eigenvalues / row means
+  double *sg = ev + 32;        // [32] signs*scale
+  int *pq = reinterpret_cast<int *>(sg + 32);  // [16]
+  int *rk = pq + 16;                           // [32]
+  const int D = K + 1;
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const double *Tg = a.T_goal + (size_t)b * D * D;
+    // goal node positions (_pose_goal, graph_revolute.py:243-249 / graph_planar.py:136-145)
+    double g0[3], g1[3];
+    for (int c = 0; c < K; ++c) {
+      g0[c] = Tg[c * D + K];
+      g1[c] = (K == 3) ? g0[c] + Tg[c * D + 2] * pc.goal_len : g0[c] - Tg[c * D + 0] * pc.goal_len;
+    }
+    for (int e = lane; e < NN; e += WAVE) {
+      const double lo = pc.base_lower[e], up = pc.base_upper[e];
+      const bool diag = (e / N) == (e % N);
+      U[e] = diag ? 0.0 : (up == up ? up : INFINITY);
+      L[e] = diag ? 0.0 : (lo == lo ? lo : -INFINITY);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 2 * pc.n_anchor) {
+      const int ai = lane >> 1, gs = lane & 1;
+      double d2 = 0.0;
+      for (int c = 0; c < K; ++c) {
+        const double df = pc.anchor_pos[ai * K + c] - (gs ? g1[c] : g0[c]);
+        d2 += df * df;
+      }
+      const double d = sqrt(d2);   // np.linalg.norm
+      gd[lane] = d;
+      const int an = pc.anchor_idx[ai], gn = gs ? pc.goal1 : pc.goal0;
+      U[an * N + gn] = U[gn * N + an] = d;
+      L[an * N + gn] = L[gn * N + an] = d;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // per-term targets: squared goal distances for the goal edges, template constants otherwise
+    for (int t = lane; t < pc.T; t += WAVE) {
+      const int src = pc.term_src[t];
+      const double g = src >= 0 ? gd[src] : 0.0;
+      a.targets[(size_t)b * pc.T + t] = src >= 0 ? g * g : pc.term_static[t];
+    }
+    // ---- bound smoothing: ub = APSP(UPPER) (Floyd-Warshall), then
+    //      lb[u][v] = max(0, max_{a,b} LOWER[a][b] - ub[u][a] - ub[b][v])   (see dgp.py)
+    for (int m = 0; m < N; ++m) {
+      for (int e = lane; e < NN; e += WAVE) {
+        const int i = e / N, j = e - i * N;
+        const double cand = U[i * N + m] + U[m * N + j];
+        if (cand < U[e]) U[e] = cand;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (int e = lane; e < NN; e += WAVE) {  // A[u][b] = max_a (L[a][b] - U[u][a])
+      const int u = e / N, bb = e - u * N;
+      double best = -INFINITY;
+      for (int q = 0; q < N; ++q) best = fmax(best, L[q * N + bb] - U[u * N + q]);
+      A[e] = best;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < NN; e += WAVE) {  // V[u][v] = lb
+      const int u = e / N, v = e - u * N;
+      double best = 0.0;
+      for (int q = 0; q < N; ++q) best = fmax(best, A[u * N + q] - U[q * N + v]);
+      V[e] = best;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- generate_initialization: D_rand = (lb + 0.9 (ub - lb))^2, Gram = -1/2 J D J
+    for (int e = lane; e < NN; e += WAVE) {
+      const double lbv = V[e], d = lbv + 0.9 * (U[e] - lbv);
+      X[e] = d * d;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < N) {
+      double s = 0.0;
+      for (int j = 0; j < N; ++j) s += X[lane * N + j];
+      ev[lane] = s / N;
+    }
+    __builtin_amdgcn_wave_barrier();
+    double mean = 0.0;
+    for (int j = 0; j < N; ++j) mean += ev[j];
+    mean /= N;
+    for (int e = lane; e < NN; e += WAVE) {
+      const int i = e / N, j = e - i * N;
+      A[e] = -0.5 * (X[e] - ev[i] - ev[j] + mean);
+      V[e] = (i == j) ? 1.0 : 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    jacobi_lds(A, V, N, a.sweeps, cs, pq, lane);
+    // ---- factor(): clip, scale by sqrt(lambda), order descending (fliplr of ascending)
+    if (lane < N) ev[lane] = A[lane * N + lane];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < N) {
+      rk[lane] = desc_rank(ev, N, lane);
+      // canonical sign: the entry of largest magnitude (first on ties) is positive.  LAPACK's
+      // sign is an implementation accident; the reference's rank rule below depends on it.
+      double big = 0.0, sgn = 1.0;
+      for (int r = 0; r < N; ++r) {
+        const double v = V[r * N + lane];
+        if (fabs(v) > big) {
+          big = fabs(v);
+          sgn = v < 0.0 ? -1.0 : 1.0;
+        }
+      }
+      sg[lane] = sgn * sqrt(fmax(ev[lane], 0.0));
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < NN; e += WAVE) {
+      const int r = e / N, c = e - r * N;
+      X[r * N + rk[c]] = V[e] * sg[c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- MDS(): K = #eigenvalues > eps of eigh(x), i.e. of the symmetric matrix read from the
+    //      LOWER triangle of the non-symmetric factor x (dgp.py:166-167, numpy UPLO='L')
+    for (int e = lane; e < NN; e += WAVE) {
+      const int i = e / N, j = e - i * N;
+      A[e] = (i >= j) ? X[i * N + j] : X[j * N + i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    jacobi_lds(A, nullptr, N, a.sweeps, cs, pq, lane);
+    int Kc = 0;
+    for (int j = 0; j < N; ++j) Kc += A[j * N + j] > 1e-8;
+    if (a.K_out && lane == 0) a.K_out[b] = Kc;
+    __builtin_amdgcn_wave_barrier();
+    // ---- linear_projection (dgp.py:174-183): scatter of the edge differences of the first Kc
+    //      columns, its top-`dim` eigenvectors
+    for (int e = lane; e < NN; e += WAVE) {
+      const int r = e / N, c = e - r * N;
+      if (c >= Kc) X[e] = 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < NN; e += WAVE) {
+      const int r = e / N, c = e - r * N;
+      double s = 0.0;
+      if (r < Kc && c < Kc) {
+        for (int p = 0; p < pc.n_pairs; ++p) {
+          const int i = pc.pair_i[p], j = pc.pair_j[p];
+          s += (X[i * N + r] - X[j * N + r]) * (X[i * N + c] - X[j * N + c]);
+        }
+      }
+      A[e] = 2.0 * s;  // the reference sums both (i,j) and (j,i)
+      V[e] = (r == c) ? 1.0 : 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    jacobi_lds(A, V, N, a.sweeps, cs, pq, lane);
+    if (lane < N) ev[lane] = (lane < Kc) ? A[lane * N + lane] : -INFINITY;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < N) {
+      rk[lane] = desc_rank(ev, N, lane);
+      double big = 0.0, sgn = 1.0;
+      for (int r = 0; r < N; ++r) {
+        const double v = V[r * N + lane];
+        if (fabs(v) > big) {
+          big = fabs(v);
+          sgn = v < 0.0 ? -1.0 : 1.0;
+        }
+      }
+      sg[lane] = sgn;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // Y = X * W, W = the K eigenvectors of largest eigenvalue
+    if (lane < N * K) {
+      const int r = lane / K, dcol = lane - r * K;
+      int col = 0;
+      for (int c = 0; c < N; ++c) col = (rk[c] == dcol) ? c : col;
+      double s = 0.0;
+      for (int c = 0; c < N; ++c) s += X[r * N + c] * V[c * N + col];
+      a.Y_init[(size_t)b * N * K + lane] = s * sg[col];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct RecoverArgs {
+  PipeConst pc;
+  const double *Y;       // [B][N*K]
+  const double *T_goal;  // [B][(K+1)^2]
+  double *q;             // [B][n]
+  double *pos_err;       // [B]
+  double *rot_err;       // [B]
+  int B;
+};
+
+__device__ inline void mat4_mul(const double *A, const double *B, double *C) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = (j == 3) ? A[i * 4 + 3] : 0.0;
+      for (int t = 0; t < 3; ++t) s += A[i * 4 + t] * B[t * 4 + j];
+      C[i * 4 + j] = s;
+    }
+  C[12] = C[13] = C[14] = 0.0;
+  C[15] = 1.0;
+}
+__device__ inline void mat4_inv_rigid(const double *A, double *C) {
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) C[i * 4 + j] = A[j * 4 + i];
+    C[i * 4 + 3] = -(A[0 * 4 + i] * A[3] + A[1 * 4 + i] * A[7] + A[2 * 4 + i] * A[11]);
+  }
+  C[12] = C[13] = C[14] = 0.0;
+  C[15] = 1.0;
+}
+__device__ inline double wrap_pi(double e) {
+  const double twopi = 6.283185307179586;
+  double m = fmod(e + 3.141592653589793, twopi);
+  if (m < 0.0) m += twopi;  // numpy mod takes the sign of the divisor
+  return m - 3.141592653589793;
+}
+
+__global__ void recover_kernel(RecoverArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const PipeConst &pc = a.pc;
+  const int N = pc.N, K = pc.K, n = pc.n_joints;
+  const double *P = a.Y + (size_t)b * N * K;
+  double *q = a.q + (size_t)b * n;
+  if (K == 3) {
+    const double *Tg = a.T_goal + (size_t)b * 16;
+    const double *p0 = P + pc.p_idx[0] * 3;
+    // base frame from the recovered anchors: R = [x^, -y^, z^]  (graph_revolute.py:263-279)
+    double R[9];
+    const int src[3] = {pc.x_idx, pc.y_idx, pc.q_idx[0]};
+    for (int c = 0; c < 3; ++c) {
+      double v[3], nr = 0.0;
+      for (int t = 0; t < 3; ++t) {
+        v[t] = P[src[c] * 3 + t] - p0[t];
+        nr += v[t] * v[t];
+      }
+      nr = sqrt(nr);
+      const double sc = (nr == 0.0 ? 1.0 : 1.0 / nr) * (c == 1 ? -1.0 : 1.0);
+      for (int t = 0; t < 3; ++t) R[t * 3 + c] = v[t] * sc;
+    }
+    double Tp[16], Trel[16], tmp[16], inv[16];
+    for (int t = 0; t < 16; ++t) Tp[t] = pc.T0[t];  // T[ROOT] = robot.T_base
+    double th = 0.0;
+    for (int idx = 1; idx <= n; ++idx) {
+      mat4_inv_rigid(pc.T0 + (idx - 1) * 16, inv);
+      mat4_mul(inv, pc.T0 + idx * 16, Trel);  // T_rel = T_prev_0^-1 T_0
+      // qs_0 = (T_prev_0^-1 T_0 trans_z(a)).trans
+      double qs0[2];
+      for (int t = 0; t < 2; ++t) qs0[t] = Trel[t * 4 + 3] + Trel[t * 4 + 2] * pc.axis_length;
+      const double *pc_ = P + pc.p_idx[idx] * 3, *qc = P + pc.q_idx[idx] * 3;
+      double dq[3], nr = 0.0;
+      for (int t = 0; t < 3; ++t) {
+        dq[t] = qc[t] - pc_[t];
+        nr += dq[t] * dq[t];
+      }
+      nr = sqrt(nr);
+      double qn[3], qb[3];
+      for (int t = 0; t < 3; ++t) qn[t] = pc_[t] + dq[t] / nr - p0[t];
+      for (int t = 0; t < 3; ++t) qb[t] = R[0 * 3 + t] * qn[0] + R[1 * 3 + t] * qn[1] + R[2 * 3 + t] * qn[2];
+      double qs[2];
+      for (int t = 0; t < 2; ++t)
+        qs[t] = Tp[0 * 4 + t] * (qb[0] - Tp[3]) + Tp[1 * 4 + t] * (qb[1] - Tp[7]) +
+                Tp[2 * 4 + t] * (qb[2] - Tp[11]);
+      th = atan2(qs0[0] * qs[1] - qs0[1] * qs[0], qs0[0] * qs[0] + qs0[1] * qs[1]);  // :308
+      q[idx - 1] = th;
+      if (idx == n) break;  // keep T_prev of the last joint for the T_final correction
+      const double c = cos(th), s = sin(th);
+      double Rz[16] = {c, -s, 0, 0, s, c, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      mat4_mul(Tp, Rz, tmp);
+      mat4_mul(tmp, Trel, Tp);  // :310
+    }
+    // T[ee] with the uncorrected last angle
+    double Tee[16];
+    {
+      const double c = cos(th), s = sin(th);
+      double Rz[16] = {c, -s, 0, 0, s, c, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      mat4_mul(Tp, Rz, tmp);
+      mat4_mul(tmp, Trel, Tee);
+    }
+    if (pc.last_along_z) {  // :314-316
+      // T_final expressed in the recovered base frame is the goal itself (T_base = identity
+      // re-basing happened at load time); T_th = T[ee]^-1 T_final
+      mat4_inv_rigid(Tee, inv);
+      mat4_mul(inv, Tg, tmp);
+      th = wrap_pi(th + atan2(tmp[4], tmp[0]));
+      q[n - 1] = th;
+      const double c = cos(th), s = sin(th);
+      double Rz[16] = {c, -s, 0, 0, s, c, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      mat4_mul(Tp, Rz, tmp);
+      mat4_mul(tmp, Trel, Tee);
+    }
+    // pose error of FK(q) = T[ee] against the goal
+    double dp = 0.0, tr = 0.0;
+    for (int t = 0; t < 3; ++t) {
+      const double df = Tg[t * 4 + 3] - Tee[t * 4 + 3];
+      dp += df * df;
+      for (int u = 0; u < 3; ++u) tr += Tg[t * 4 + u] * Tee[t * 4 + u];  // trace(Rg Rs^T)
+    }
+    a.pos_err[b] = sqrt(dp);
+    a.rot_err[b] = acos(fmin(1.0, fmax(-1.0, 0.5 * tr - 0.5)));
+  } else {
+    const double *Tg = a.T_goal + (size_t)b * 9;
+    // best_fit_transform of (p0, x, y) onto ((0,0), (-1,0), (0,1)) without reflection handling
+    const double *A0 = P + pc.p_idx[0] * 2, *A1 = P + pc.x_idx * 2, *A2 = P + pc.y_idx * 2;
+    const double ca[2] = {(A0[0] + A1[0] + A2[0]) / 3.0, (A0[1] + A1[1] + A2[1]) / 3.0};
+    const double Bp[3][2] = {{0, 0}, {-1, 0}, {0, 1}};
+    const double cb[2] = {-1.0 / 3.0, 1.0 / 3.0};
+    const double *Ap[3] = {A0, A1, A2};
+    double H[4] = {0, 0, 0, 0};  // H = AA^T BB
+    for (int t = 0; t < 3; ++t)
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) H[i * 2 + j] += (Ap[t][i] - ca[i]) * (Bp[t][j] - cb[j]);
+    // R = V U^T (H = U S V^T) = orthogonal polar factor of H^T; M = H^T
+    const double M00 = H[0], M01 = H[2], M10 = H[1], M11 = H[3];
+    const double det = M00 * M11 - M01 * M10;
+    double Rm[4];
+    if (det >= 0.0) {
+      const double ang = atan2(M10 - M01, M00 + M11);
+      Rm[0] = cos(ang); Rm[1] = -sin(ang); Rm[2] = sin(ang); Rm[3] = cos(ang);
+    } else {
+      const double ang = atan2(M10 + M01, M00 - M11);
+      Rm[0] = cos(ang); Rm[1] = sin(ang); Rm[2] = sin(ang); Rm[3] = -cos(ang);
+    }
+    double Rc[4] = {1, 0, 0, 1};
+    // FK of the recovered angles: T_i = T_{i-1} Rz(q_i) T0_{i-1}^-1 T0_i  (robot_planar.py:62-80)
+    double Fr[4] = {pc.T0[0], pc.T0[1], pc.T0[3], pc.T0[4]}, Ft[2] = {pc.T0[2], pc.T0[5]};
+    for (int i = 1; i <= n; ++i) {
+      const double *pu = P + pc.p_idx[i - 1] * 2, *pv = P + pc.p_idx[i] * 2;
+      const double d0 = pv[0] - pu[0], d1 = pv[1] - pu[1];
+      double f0 = Rm[0] * d0 + Rm[1] * d1, f1 = Rm[2] * d0 + Rm[3] * d1;
+      const double len = sqrt(f0 * f0 + f1 * f1);
+      f0 /= len;
+      f1 /= len;
+      const double s0 = Rc[0] * f0 + Rc[2] * f1, s1 = Rc[1] * f0 + Rc[3] * f1;  // R[u]^T f
+      const double th = atan2(s1, s0);
+      q[i - 1] = wrap_pi(th);
+      const double c = cos(th), s = sin(th);
+      const double n0 = Rc[0] * c + Rc[1] * s, n1 = -Rc[0] * s + Rc[1] * c;
+      const double n2 = Rc[2] * c + Rc[3] * s, n3 = -Rc[2] * s + Rc[3] * c;
+      Rc[0] = n0; Rc[1] = n1; Rc[2] = n2; Rc[3] = n3;
+      // T_rel = T0_{i-1}^-1 T0_i
+      const double *Ta = pc.T0 + (i - 1) * 9, *Tb = pc.T0 + i * 9;
+      const double a00 = Ta[0], a01 = Ta[1], a10 = Ta[3], a11 = Ta[4];
+      const double dxr = Tb[2] - Ta[2], dyr = Tb[5] - Ta[5];
+      const double rr[4] = {a00 * Tb[0] + a10 * Tb[3], a00 * Tb[1] + a10 * Tb[4],
+                            a01 * Tb[0] + a11 * Tb[3], a01 * Tb[1] + a11 * Tb[4]};
+      const double rt[2] = {a00 * dxr + a10 * dyr, a01 * dxr + a11 * dyr};
+      const double cq = cos(q[i - 1]), sq = sin(q[i - 1]);
+      // F <- F * Rz(q) * T_rel
+      const double g0 = Fr[0] * cq + Fr[1] * sq, g1 = -Fr[0] * sq + Fr[1] * cq;
+      const double g2 = Fr[2] * cq + Fr[3] * sq, g3 = -Fr[2] * sq + Fr[3] * cq;
+      Ft[0] += g0 * rt[0] + g1 * rt[1];
+      Ft[1] += g2 * rt[0] + g3 * rt[1];
+      Fr[0] = g0 * rr[0] + g1 * rr[2]; Fr[1] = g0 * rr[1] + g1 * rr[3];
+      Fr[2] = g2 * rr[0] + g3 * rr[2]; Fr[3] = g2 * rr[1] + g3 * rr[3];
+    }
+    const double px = Ft[0], py = Ft[1], phi = atan2(Fr[2], Fr[0]);
+    const double dx = Tg[2] - px, dy = Tg[5] - py;
+    a.pos_err[b] = sqrt(dx * dx + dy * dy);
+    const double gphi = atan2(Tg[3], Tg[0]);
+    a.rot_err[b] = fabs(wrap_pi(gphi - phi));
+  }
+}
+
+}  // namespace gik

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "gik_prep.hip.h"
 #include "gik_wave.hip.h"
 #include "graphik_amd.h"
 
@@ -323,8 +324,27 @@ struct gik_template {
   int n_cu;
   int waves_per_cu;  // resident solve wavefronts per CU (from the occupancy query)
   size_t smem_bytes;
+  // device pre/post-processing (gik_pipeline_attach)
+  bool has_pipe;
+  gik::PipeConst pc;
+  std::vector<void *> pipe_allocs;
+  size_t prep_smem;
+  int sweeps;
 };
 static constexpr int kCounterRing = 256;
+
+template <typename T>
+static const T *upload(gik_template *t, const T *host, size_t count, bool &ok) {
+  if (count == 0 || !host) return nullptr;
+  void *d = nullptr;
+  if (hipMalloc(&d, count * sizeof(T)) != hipSuccess ||
+      hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+    ok = false;
+    return nullptr;
+  }
+  t->pipe_allocs.push_back(d);
+  return static_cast<const T *>(d);
+}
 
 extern "C" {
 
@@ -416,6 +436,7 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   t->d_slot_meta = nullptr;
   t->d_counters = nullptr;
   t->next_counter = 0;
+  t->has_pipe = false;
   t->smem_bytes = var->lds(T);
   hipDeviceProp_t prop;
   int occ = 0;
@@ -442,7 +463,106 @@ void gik_template_destroy(gik_template *t) {
   if (!t) return;
   if (t->d_slot_meta) (void)hipFree(t->d_slot_meta);
   if (t->d_counters) (void)hipFree(t->d_counters);
+  for (void *p : t->pipe_allocs) (void)hipFree(p);
   delete t;
+}
+
+int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
+  using namespace gik;
+  if (!t || !d) return fail("null argument");
+  if (t->has_pipe) return fail("pipeline already attached");
+  const int N = t->N, K = t->K, n = d->n_joints;
+  if (n < 1 || n > 31) return fail("n_joints out of range");
+  if (d->n_anchor < 1 || d->n_anchor > 32) return fail("n_anchor must be in [1, 32]");
+  if (!d->T0 || !d->p_index || !d->base_lower || !d->base_upper || !d->anchor_index ||
+      !d->anchor_pos || !d->pair_i || !d->pair_j || !d->term_src || !d->term_static)
+    return fail("null pipeline array");
+  if (K == 3 && !d->q_index) return fail("q_index required for k=3");
+  bool ok = true;
+  PipeConst pc;
+  const int DD = (K + 1) * (K + 1);
+  pc.T0 = upload(t, d->T0, (size_t)(n + 1) * DD, ok);
+  pc.p_idx = upload(t, d->p_index, n + 1, ok);
+  pc.q_idx = (K == 3) ? upload(t, d->q_index, n + 1, ok) : pc.p_idx;
+  pc.base_lower = upload(t, d->base_lower, (size_t)N * N, ok);
+  pc.base_upper = upload(t, d->base_upper, (size_t)N * N, ok);
+  pc.anchor_idx = upload(t, d->anchor_index, d->n_anchor, ok);
+  pc.anchor_pos = upload(t, d->anchor_pos, (size_t)d->n_anchor * K, ok);
+  pc.pair_i = upload(t, d->pair_i, d->n_pairs, ok);
+  pc.pair_j = upload(t, d->pair_j, d->n_pairs, ok);
+  pc.term_src = upload(t, d->term_src, t->T, ok);
+  pc.term_static = upload(t, d->term_static, t->T, ok);
+  if (!ok) return fail("device upload failed");
+  pc.N = N;
+  pc.K = K;
+  pc.T = t->T;
+  pc.n_anchor = d->n_anchor;
+  pc.n_pairs = d->n_pairs;
+  pc.n_joints = n;
+  pc.goal0 = d->goal_node0;
+  pc.goal1 = d->goal_node1;
+  pc.x_idx = d->x_index;
+  pc.y_idx = d->y_index;
+  pc.goal_len = d->goal_len;
+  pc.axis_length = d->axis_length;
+  pc.last_along_z = d->last_link_along_z;
+  t->pc = pc;
+  t->sweeps = d->jacobi_sweeps > 0 ? d->jacobi_sweeps : 10;
+  t->prep_smem = sizeof(double) * ((size_t)5 * N * N + 2 * d->n_anchor + 96) + sizeof(int) * 48;
+  t->has_pipe = true;
+  return 0;
+}
+
+int gik_prepare_batch(const gik_template *t, const double *d_T_goal, int B, double *d_targets,
+                      double *d_Y_init, int32_t *d_K_out, void *stream) {
+  using namespace gik;
+  if (!t || B < 0) return fail("bad argument");
+  if (!t->has_pipe) return fail("no pipeline attached (gik_pipeline_attach)");
+  if (B == 0) return 0;
+  if (!d_T_goal || !d_targets || !d_Y_init) return fail("null buffer");
+  PrepArgs a;
+  a.pc = t->pc;
+  a.T_goal = d_T_goal;
+  a.targets = d_targets;
+  a.Y_init = d_Y_init;
+  a.K_out = d_K_out;
+  a.B = B;
+  a.sweeps = t->sweeps;
+  const int grid = std::min(B, t->n_cu * 8);
+  hipLaunchKernelGGL(prep_wave_kernel, dim3(grid), dim3(WAVE), t->prep_smem, (hipStream_t)stream,
+                     a);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int gik_recover_batch(const gik_template *t, const double *d_Y, const double *d_T_goal, int B,
+                      double *d_q, double *d_pos_err, double *d_rot_err, void *stream) {
+  using namespace gik;
+  if (!t || B < 0) return fail("bad argument");
+  if (!t->has_pipe) return fail("no pipeline attached (gik_pipeline_attach)");
+  if (B == 0) return 0;
+  if (!d_Y || !d_T_goal || !d_q || !d_pos_err || !d_rot_err) return fail("null buffer");
+  RecoverArgs a;
+  a.pc = t->pc;
+  a.Y = d_Y;
+  a.T_goal = d_T_goal;
+  a.q = d_q;
+  a.pos_err = d_pos_err;
+  a.rot_err = d_rot_err;
+  a.B = B;
+  hipLaunchKernelGGL(recover_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int gik_ik_batch(const gik_template *t, const double *d_T_goal, int B, double *d_targets,
+                 double *d_Y, gik_stats *d_stats, double *d_q, double *d_pos_err,
+                 double *d_rot_err, void *stream) {
+  int rc = gik_prepare_batch(t, d_T_goal, B, d_targets, d_Y, nullptr, stream);
+  if (rc) return rc;
+  rc = gik_solve_batch(t, d_Y, d_targets, B, d_Y, d_stats, nullptr, stream);
+  if (rc) return rc;
+  return gik_recover_batch(t, d_Y, d_T_goal, B, d_q, d_pos_err, d_rot_err, stream);
 }
 
 static int launch_kat(const gik_template *t, int mode, const double *d_Y, const double *d_W,

@@ -172,6 +172,101 @@ class Template:
                                          self._stream()))
         return out.reshape(B, self.N, self.k)
 
+    # -- device pre/post-processing ----------------------------------------------------------
+    def attach_pipeline(self, *, T0, p_index, q_index, x_index, y_index, axis_length, goal_nodes,
+                        goal_len, base_lower, base_upper, anchor_index, anchor_pos, pair_i, pair_j,
+                        term_src, term_static, last_link_along_z, jacobi_sweeps=0):
+        """Give the handle what it needs to run from_pose + bound_smoothing +
+        generate_initialization and joint_variables on the device (gik_pipeline_attach)."""
+        keep = {}
+
+        def arr(name, a, dt):
+            keep[name] = np.ascontiguousarray(a, dtype=dt)
+            ct = C.c_double if dt == np.float64 else C.c_int32
+            return keep[name].ctypes.data_as(C.POINTER(ct))
+
+        d = _ffi.PipelineDesc()
+        T0 = np.asarray(T0, dtype=np.float64)
+        d.n_joints = T0.shape[0] - 1
+        d.T0 = arr("T0", T0, np.float64)
+        d.p_index = arr("p", p_index, np.int32)
+        d.q_index = arr("q", q_index if q_index is not None else p_index, np.int32)
+        d.x_index, d.y_index = int(x_index), int(y_index)
+        d.axis_length = float(axis_length)
+        d.goal_node0, d.goal_node1 = int(goal_nodes[0]), int(goal_nodes[1])
+        d.goal_len = float(goal_len)
+        d.base_lower = arr("lo", base_lower, np.float64)
+        d.base_upper = arr("up", base_upper, np.float64)
+        d.n_anchor = len(anchor_index)
+        d.anchor_index = arr("ai", anchor_index, np.int32)
+        d.anchor_pos = arr("ap", anchor_pos, np.float64)
+        d.n_pairs = len(pair_i)
+        d.pair_i = arr("pi", pair_i, np.int32)
+        d.pair_j = arr("pj", pair_j, np.int32)
+        d.term_src = arr("ts", term_src, np.int32)
+        d.term_static = arr("tv", term_static, np.float64)
+        d.last_link_along_z = int(bool(last_link_along_z))
+        d.jacobi_sweeps = int(jacobi_sweeps)
+        with torch.cuda.device(self.device):
+            _ffi.check(self.lib.gik_pipeline_attach(self._h, C.byref(d)))
+        self.n_joints = int(d.n_joints)
+        self.has_pipeline = True
+
+    def _poses(self, T_goal):
+        T = _dev(T_goal, self.device)
+        B = T.shape[0]
+        return T.reshape(B, (self.k + 1) ** 2).contiguous(), B
+
+    def prepare(self, T_goal, return_K=False):
+        """goal poses [B,k+1,k+1] -> (targets [B,T], Y_init [B,N,k]) on the device."""
+        T, B = self._poses(T_goal)
+        targets = torch.empty(B, self.T, dtype=torch.float64, device=self.device)
+        Y0 = torch.empty(B, self.N * self.k, dtype=torch.float64, device=self.device)
+        Kc = torch.zeros(B, dtype=torch.int32, device=self.device) if return_K else None
+        with torch.cuda.device(self.device):
+            _ffi.check(self.lib.gik_prepare_batch(self._h, T.data_ptr(), B, targets.data_ptr(),
+                                                  Y0.data_ptr(),
+                                                  Kc.data_ptr() if return_K else None,
+                                                  self._stream()))
+        Y0 = Y0.reshape(B, self.N, self.k)
+        return (targets, Y0, Kc) if return_K else (targets, Y0)
+
+    def recover(self, Y, T_goal):
+        """points + goal poses -> (q [B,n], pos_err [B], rot_err [B]) on the device."""
+        Y, B = self._vec(Y)
+        T, _ = self._poses(T_goal)
+        q = torch.empty(B, self.n_joints, dtype=torch.float64, device=self.device)
+        pe = torch.empty(B, dtype=torch.float64, device=self.device)
+        re = torch.empty(B, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _ffi.check(self.lib.gik_recover_batch(self._h, Y.data_ptr(), T.data_ptr(), B,
+                                                  q.data_ptr(), pe.data_ptr(), re.data_ptr(),
+                                                  self._stream()))
+        return q, pe, re
+
+    def ik(self, T_goal, out=None):
+        """Whole solve_with_riemannian pipeline for a batch of goal poses, one stream, no host
+        round trip: prepare -> solve -> recover.  Returns a dict of device tensors."""
+        T, B = self._poses(T_goal)
+        if out is None:
+            out = self.alloc_ik_buffers(B)
+        with torch.cuda.device(self.device):
+            _ffi.check(self.lib.gik_ik_batch(self._h, T.data_ptr(), B, out["targets"].data_ptr(),
+                                             out["Y"].data_ptr(), out["stats"].data_ptr(),
+                                             out["q"].data_ptr(), out["pos_err"].data_ptr(),
+                                             out["rot_err"].data_ptr(), self._stream()))
+        ints = out["stats"].view(torch.int32)
+        return {"x": out["Y"].reshape(B, self.N, self.k), "q": out["q"], "pos_err": out["pos_err"],
+                "rot_err": out["rot_err"], "f": out["stats"][:, 0], "gradnorm": out["stats"][:, 1],
+                "iterations": ints[:, 4], "inner_total": ints[:, 5], "stop": ints[:, 6],
+                "n_accept": ints[:, 7]}
+
+    def alloc_ik_buffers(self, B):
+        f64 = dict(dtype=torch.float64, device=self.device)
+        return {"targets": torch.empty(B, self.T, **f64), "Y": torch.empty(B, self.N * self.k, **f64),
+                "stats": torch.zeros(B, 4, **f64), "q": torch.empty(B, self.n_joints, **f64),
+                "pos_err": torch.empty(B, **f64), "rot_err": torch.empty(B, **f64)}
+
     # -- trust-region solve -------------------------------------------------------------------
     def solve(self, Y_init, targets, trace_cap=0):
         """Batched TrustRegions.solve.  Returns dict of device tensors:

@@ -156,6 +156,53 @@ class BatchProblem:
         self.template = Template.from_matrices(self.omega, self.psi_L, self.psi_U, k=self.dim,
                                                use_limits=use_limits, device=device, params=params)
         self.N = N
+        self._attach_device_pipeline()
+
+    def _attach_device_pipeline(self):
+        """Hand the goal-independent pre/post-processing data to the device handle."""
+        g, T = self.graph, self.template
+        n = self.robot.n
+        if len(self.anchor_nodes) > 32 or self.N > 32:
+            self.device_pipeline = False   # obstacle-laden graphs: host pre/post (block path)
+            return
+        goalset = set(self.goal_nodes)
+        slot = {a: s for s, a in enumerate(self.anchor_nodes)}
+        term_src = np.full(T.T, -1, dtype=np.int32)
+        for t in range(T.T):
+            i, j = int(T.term_i[t]), int(T.term_j[t])
+            if T.term_kind[t] != 1:
+                continue
+            for a, gnode in ((i, j), (j, i)):
+                if gnode in goalset and a in slot:
+                    term_src[t] = slot[a] * 2 + self.goal_nodes.index(gnode)
+        static = np.where(np.isnan(T.targets_static), self.base_D[T.term_i, T.term_j],
+                          T.targets_static)
+        lower = self.base_lower.copy()
+        upper = self.base_upper.copy()
+        for a in self.anchor_nodes:   # goal edges are re-created per goal on the device
+            for gnode in self.goal_nodes:
+                lower[a, gnode] = lower[gnode, a] = np.nan
+                upper[a, gnode] = upper[gnode, a] = np.nan
+        I, J = np.nonzero(np.triu(self.omega))
+        T0 = self.robot.T0_array()
+        if self.dim == 3:
+            p_idx = [g.index(f"p{i}") for i in range(n + 1)]
+            q_idx = [g.index(f"q{i}") for i in range(n + 1)]
+            rel_last = np.linalg.inv(T0[n - 1]) @ T0[n]
+            along_z = np.linalg.norm(np.cross(rel_last[:3, 3], [0, 0, 1])) < 1e-10
+            goal_len = g.axis_length
+        else:
+            p_idx = [g.index(f"p{i}") for i in range(n + 1)]
+            q_idx = None
+            along_z = False
+            goal_len = g.dist[self.goal_nodes[1], self.goal_nodes[0]]
+        T.attach_pipeline(T0=T0, p_index=p_idx, q_index=q_idx, x_index=g.index("x"),
+                          y_index=g.index("y"), axis_length=g.axis_length,
+                          goal_nodes=self.goal_nodes, goal_len=goal_len, base_lower=lower,
+                          base_upper=upper, anchor_index=self.anchor_nodes,
+                          anchor_pos=self.anchor_pos, pair_i=I, pair_j=J, term_src=term_src,
+                          term_static=static, last_link_along_z=along_z)
+        self.device_pipeline = True
 
     def goal_positions(self, T_goals):
         """[B,d+1,d+1] poses -> positions of the goal nodes [B,2,d]  (_pose_goal)."""
@@ -234,16 +281,26 @@ def solve_batch(graph, T_goals, use_limits=True, params=None, device=None, Y_ini
     T = np.stack([as_matrix(t) for t in T_goals]) if not isinstance(T_goals, np.ndarray) \
         else np.asarray(T_goals, dtype=float)
     prob = _problem_for(graph, use_limits, params, device)
-    targets, Y0 = prob.prepare(T)
-    if Y_init is not None:
-        Y0 = np.asarray(Y_init, dtype=float)
     t0 = time.time()
-    res = prob.template.solve(Y0, targets)
-    torch.cuda.synchronize(prob.template.device)
-    dt = time.time() - t0
-    Y = res["x"].cpu().numpy()
-    q = prob.joint_variables(Y, T)
-    pos, rot = prob.pose_errors(q, T)
+    if prob.device_pipeline and Y_init is None:
+        # everything on the device: prepare -> solve -> recover (gik_ik_batch)
+        res = prob.template.ik(T)
+        torch.cuda.synchronize(prob.template.device)
+        dt = time.time() - t0
+        Y = res["x"].cpu().numpy()
+        q = res["q"].cpu().numpy()
+        pos, rot = res["pos_err"].cpu().numpy(), res["rot_err"].cpu().numpy()
+    else:
+        targets, Y0 = prob.prepare(T)
+        if Y_init is not None:
+            Y0 = np.asarray(Y_init, dtype=float)
+        t0 = time.time()
+        res = prob.template.solve(Y0, targets)
+        torch.cuda.synchronize(prob.template.device)
+        dt = time.time() - t0
+        Y = res["x"].cpu().numpy()
+        q = prob.joint_variables(Y, T)
+        pos, rot = prob.pose_errors(q, T)
     info = {"x": Y, "f(x)": res["f"].cpu().numpy(), "gradnorm": res["gradnorm"].cpu().numpy(),
             "iterations": res["iterations"].cpu().numpy(),
             "inner_iterations": res["inner_total"].cpu().numpy(),

@@ -135,12 +135,26 @@ def generate_initialization(bounds, dim, omega):
     return linear_projection(X_rand, omega, dim)
 
 
-def generate_initialization_batch(lb, ub, dim, omega):
-    """Vectorised generate_initialization: lb, ub [B,N,N] -> Y_init [B,N,dim]."""
+def _canonical_signs(V):
+    """Flip each eigenvector (column) so that its entry of largest magnitude is positive."""
+    idx = np.argmax(np.abs(V), axis=-2)
+    sgn = np.sign(np.take_along_axis(V, idx[..., None, :], axis=-2))
+    return V * np.where(sgn == 0, 1.0, sgn)
+
+
+def generate_initialization_batch(lb, ub, dim, omega, canonical=False):
+    """Vectorised generate_initialization: lb, ub [B,N,N] -> Y_init [B,N,dim].
+
+    canonical=False keeps LAPACK's eigenvector signs (what the reference gets).  The column count
+    K of MDS() is the number of positive eigenvalues of a matrix built from the LOWER TRIANGLE of
+    the eigenvector factor, so it depends on those arbitrary signs; canonical=True fixes them by
+    a rule (largest-magnitude entry positive), which is what the device kernel implements."""
     B, N, _ = lb.shape
     D = (lb + 0.9 * (ub - lb)) ** 2
     G = gram_from_distance_matrix(D)
     ev, V = np.linalg.eigh(G)
+    if canonical:
+        V = _canonical_signs(V)
     ev = np.where(ev < 0, 0.0, ev)
     X = (V * np.sqrt(ev)[:, None, :])[:, :, ::-1]
     ev2 = np.linalg.eigvalsh(X)  # lower triangle, like numpy's default UPLO='L'
@@ -150,4 +164,6 @@ def generate_initialization_batch(lb, ub, dim, omega):
     d = X[:, I, :] - X[:, J, :]
     S = np.einsum("bek,bel->bkl", d, d)
     _, W = np.linalg.eigh(S)
+    if canonical:
+        W = _canonical_signs(W)
     return X @ W[:, :, ::-1][:, :, :dim]

@@ -116,6 +116,54 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
                     int B, double *d_Y_out, gik_stats *d_stats, const gik_trace *trace,
                     void *stream);
 
+/* ---- whole solve_with_riemannian pipeline on the device ------------------------------------
+ * Goal-independent description of the per-goal pre/post-processing of
+ * solve_with_riemannian (riemannian_solver.py:220-234): how a goal pose pins the goal nodes
+ * (graph_revolute.py:243-249 / graph_planar.py:136-145), the LOWER/UPPER attributes bound
+ * smoothing runs on (dgp.py:192-231), the omega pairs of linear_projection (dgp.py:174-183),
+ * and the robot frames joint_variables needs (graph_revolute.py:251-318).                   */
+typedef struct {
+  int32_t n_joints;          /* n                                                          */
+  const double *T0;          /* [(n+1)][(k+1)*(k+1)] frames at zero configuration, row-major */
+  const int32_t *p_index;    /* [n+1] node index of p_i                                    */
+  const int32_t *q_index;    /* [n+1] node index of q_i (k=3; ignored for k=2)             */
+  int32_t x_index, y_index;  /* base anchor nodes "x", "y"                                 */
+  double axis_length;        /* graph.axis_length                                          */
+  int32_t goal_node0;        /* node pinned at the goal position (p_n)                     */
+  int32_t goal_node1;        /* q_n (k=3: p_n + axis_length*z) or p_{n-1} (k=2: p_n - len*x) */
+  double goal_len;           /* axis_length (k=3) / DIST(p_{n-1}, p_n) (k=2)               */
+  const double *base_lower;  /* [N*N] LOWER of the goal-independent edges, NaN = no edge   */
+  const double *base_upper;  /* [N*N] UPPER                                                */
+  int32_t n_anchor;          /* nodes with a known position besides the goal nodes (<= 32) */
+  const int32_t *anchor_index; /* [n_anchor]                                               */
+  const double *anchor_pos;  /* [n_anchor][k]                                              */
+  int32_t n_pairs;           /* omega pairs (i<j) of the goal graph                        */
+  const int32_t *pair_i, *pair_j;
+  const int32_t *term_src;   /* [T] -1: term_static[t]; else anchor_slot*2 + goal_slot     */
+  const double *term_static; /* [T] psi_L / psi_U / goal-independent squared distances     */
+  int32_t last_link_along_z; /* the T_final correction of graph_revolute.py:314-316 applies */
+  int32_t jacobi_sweeps;     /* 0 = default (10)                                           */
+} gik_pipeline_desc;
+
+int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *desc);
+
+/* goal poses [B][(k+1)^2] (row-major homogeneous matrices) -> per-term targets [B][T] and the
+ * initial point [B][N*k] (from_pose + bound_smoothing + generate_initialization).
+ * d_K_out (optional, [B] int32): the MDS column count chosen per goal.                     */
+int gik_prepare_batch(const gik_template *t, const double *d_T_goal, int B, double *d_targets,
+                      double *d_Y_init, int32_t *d_K_out, void *stream);
+
+/* points [B][N*k] + goal poses -> joint angles [B][n], EE position / rotation error of
+ * FK(q) against the goal [B] (joint_variables + robot.pose + the examples' error metric).  */
+int gik_recover_batch(const gik_template *t, const double *d_Y, const double *d_T_goal, int B,
+                      double *d_q, double *d_pos_err, double *d_rot_err, void *stream);
+
+/* prepare + solve + recover on one stream.  d_Y [B][N*k] receives the solution points and
+ * doubles as the Y_init buffer; d_targets [B][T] is caller-provided scratch.               */
+int gik_ik_batch(const gik_template *t, const double *d_T_goal, int B, double *d_targets,
+                 double *d_Y, gik_stats *d_stats, double *d_q, double *d_pos_err,
+                 double *d_rot_err, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
