@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  (ordering matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgraphik_amd.so")
+LIB_PATH = os.environ.get("GIK_LIB_PATH") or os.path.join(_HERE, "lib", "libgraphik_amd.so")
 
 TERM_EQ, TERM_LOWER, TERM_UPPER = 1, 2, 3
 ABI_VERSION = 1

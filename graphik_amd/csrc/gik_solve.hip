@@ -54,6 +54,19 @@ __device__ inline void stage_lds(double *tiles, uint32_t *meta, const uint32_t *
   __builtin_amdgcn_wave_barrier();
 }
 
+// ||g||_F together with <g, pk2_m> in one reduction
+template <typename Ctx>
+__device__ inline double grad_norm_and_rho(const Ctx &cx, double g, double (&rho0)[Ctx::NC]) {
+  double v[Ctx::NC + 1];
+  v[0] = g * g;
+#pragma unroll
+  for (int m = 0; m < Ctx::NC; ++m) v[m + 1] = g * cx.pk2[m];
+  wave_sum_n<Ctx::NC + 1>(v);
+#pragma unroll
+  for (int m = 0; m < Ctx::NC; ++m) rho0[m] = v[m + 1];
+  return sqrt(v[0]);
+}
+
 // Persistent kernel: grid = (resident waves), each wavefront claims IK problems from a global
 // counter until the batch is exhausted.  Iteration counts differ by >50x between goals and the
 // hardware hands workgroups to XCDs round-robin, so a static block->problem map leaves whole
@@ -94,7 +107,9 @@ __global__ void __launch_bounds__(WAVE) rtr_wave_kernel(SolveArgs a) {
     double fx = cx.cost(x);                 // :159
     double g = cx.commit();                 // :160  (also loads the slot constants at x)
     cx.proj_setup(p.planar_proj_exact);
-    double norm_grad = sqrt(wave_sum(g * g));  // :161
+    // ||grad|| (:161) and rho0_m = <grad, pk2_m> (start values of the tCG recurrences)
+    double rho0[Ctx::NC];
+    double norm_grad = grad_norm_and_rho(cx, g, rho0);
     int kiter = 0, inner_total = 0, n_accept = 0, stop = 1;
     bool bad = UNI(!(fx == fx) || !(norm_grad == norm_grad));
     if (a.dbg & 2) bad = true;
@@ -112,12 +127,18 @@ __global__ void __launch_bounds__(WAVE) rtr_wave_kernel(SolveArgs a) {
       double delta = -r;                         // :469
       double e_Pd = 0.0, model_value = 0.0;      // :471,485
       int stop_tCG = TCG_MAX_INNER_ITER;         // :491
+      double rho_pk[Ctx::NC], s_pk[Ctx::NC], hd_pk[Ctx::NC];  // <r,pk2>, <delta,pk2>, <Hdelta,pk2>
+#pragma unroll
+      for (int m = 0; m < Ctx::NC; ++m) {
+        rho_pk[m] = rho0[m];
+        s_pk[m] = -rho0[m];
+      }
       int j = 0;
       for (j = 0; j < p.maxinner; ++j) {         // :495
         double d_Hd;
-        const double Hdelta = cx.hess_proj_dot(delta, d_Hd);  // :497-500
+        const double Hdelta = cx.hess_proj_dot(delta, s_pk, d_Hd, hd_pk);  // :497-500
         if (UNI(!(d_Hd == d_Hd))) { bad = true; break; }
-        const double alpha = z_r / d_Hd;                  // :503
+        const double alpha = fdiv(z_r, d_Hd);             // :503
         const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;  // :506
         if (UNI(d_Hd <= 0.0 || e_Pe_new >= Delta * Delta)) {   // :509
           const double tau =
@@ -155,8 +176,13 @@ __global__ void __launch_bounds__(WAVE) rtr_wave_kernel(SolveArgs a) {
         }
         const double zold_rold = z_r;                     // :587
         z_r = r_r;                                        // :589
-        const double beta = z_r / zold_rold;              // :592
+        const double beta = fdiv(z_r, zold_rold);         // :592
         delta = -r + beta * delta;                        // :593
+#pragma unroll
+        for (int m = 0; m < Ctx::NC; ++m) {               // the same two updates seen through pk2
+          rho_pk[m] = fma(alpha, hd_pk[m], rho_pk[m]);
+          s_pk[m] = fma(beta, s_pk[m], -rho_pk[m]);
+        }
         e_Pd = beta * (e_Pd + alpha * d_Pd);              // :596
         d_Pd = z_r + beta * beta * d_Pd;                  // :597
       }
@@ -198,7 +224,7 @@ __global__ void __launch_bounds__(WAVE) rtr_wave_kernel(SolveArgs a) {
         fx = fx_prop;                                    // :386
         g = cx.commit();                                 // :387 (rows of x_prop are in LDS)
         cx.proj_setup(p.planar_proj_exact);
-        norm_grad = sqrt(wave_sum(g * g));               // :388
+        norm_grad = grad_norm_and_rho(cx, g, rho0);      // :388
       }
       if (a.has_trace && kiter < a.trace.cap && lane == 0) {
         const size_t q = (size_t)b * a.trace.cap + kiter;
@@ -276,6 +302,75 @@ __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
     res = cx.proj(w);
   }
   if (cx.active) a.out[(size_t)b * NK + lane] = res;
+}
+
+// ------------------------------------------------------------------------------------------
+// developer micro-benchmark: per-component cycle cost of one wavefront (not part of the ABI)
+template <int K, int MAXDEG>
+__global__ void __launch_bounds__(WAVE) parts_kernel(const uint32_t *slot_meta, int N, int T, int mode,
+                                                     int iters, double *out) {
+  using Ctx = WaveCtx<K, MAXDEG>;
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x;
+  double *sh_tiles = smem;
+  double *sh_tgt = smem + K * Ctx::TILE;
+  uint32_t *sh_meta = reinterpret_cast<uint32_t *>(sh_tgt + ((T + 1) & ~1));
+  stage_lds<Ctx>(sh_tiles, sh_meta, slot_meta, lane, MAXDEG, K);
+  for (int t = lane; t < T; t += WAVE) sh_tgt[t] = 1.0 + 0.01 * t;
+  Ctx cx;
+  cx.init(lane, N, sh_tiles, sh_tgt, sh_meta);
+  double x = cx.active ? 0.37 * lane - 0.01 * lane * lane : 0.0;
+  (void)cx.cost(x);
+  double g = cx.commit();
+  cx.proj_setup(0);
+  double acc = g, sc = 1.0;
+  const long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    if (mode == 0) {            // ehess only
+      acc = cx.ehess(acc) * 1e-3 + g;
+    } else if (mode == 1) {     // 3-value reduction
+      double v[3] = {acc, acc * 0.5, acc * 0.25};
+      wave_sum_n<3>(v);
+      acc = g + 1e-3 * (v[0] + v[1] + v[2]);
+    } else if (mode == 2) {     // 1-value reduction
+      acc = g + 1e-3 * wave_sum(acc);
+    } else if (mode == 3) {     // fp64 division chain
+      sc = 1.0 / (sc + 1.5);
+      acc = acc + sc;
+    } else if (mode == 4) {     // proj(ehess)
+      acc = cx.proj(cx.ehess(acc)) * 1e-3 + g;
+    } else if (mode == 5) {     // dependent fma chain (8 per iteration)
+      for (int q = 0; q < 8; ++q) acc = fma(acc, 0.999, g);
+    } else if (mode == 6) {     // sqrt chain
+      sc = sqrt(sc + 1.5);
+      acc = acc + sc;
+    } else if (mode == 7) {     // 8 independent fma chains x 8 (64 fma / iteration)
+      double c0 = acc, c1 = acc + 1, c2 = acc + 2, c3 = acc + 3, c4 = acc + 4, c5 = acc + 5,
+             c6 = acc + 6, c7 = acc + 7;
+      for (int q = 0; q < 8; ++q) {
+        c0 = fma(c0, 0.999, g); c1 = fma(c1, 0.999, g); c2 = fma(c2, 0.999, g);
+        c3 = fma(c3, 0.999, g); c4 = fma(c4, 0.999, g); c5 = fma(c5, 0.999, g);
+        c6 = fma(c6, 0.999, g); c7 = fma(c7, 0.999, g);
+      }
+      acc = ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7));
+    } else if (mode == 8) {     // LDS write + dependent read round trip
+      cx.put(acc);
+      acc = cx.read_row(cx.own_off).v[1] + g;
+    } else if (mode == 9) {     // one DPP move + add (dependent)
+      acc = acc + dpp_f64<0xB1>(acc) * 1e-3;
+    } else if (mode == 10) {    // readlane + add (dependent)
+      acc = g + readlane_f64(acc, 17) * 1e-3;
+    } else if (mode == 11) {    // 8 dependent f32 fma
+      float fa = (float)acc;
+      for (int q = 0; q < 8; ++q) fa = fmaf(fa, 0.999f, 0.5f);
+      acc = fa;
+    }
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  if (lane == 0) {
+    out[0] = (double)(t1 - t0) / iters;
+    out[1] = acc + sc;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -650,6 +745,30 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
                      (hipStream_t)stream, a);
   HIP_OK(hipGetLastError());
   return 0;
+}
+
+// developer hook (not part of the ABI header): cycles per iteration of one kernel component
+double gik_debug_parts(const gik_template *t, int mode, int iters) {
+  using namespace gik;
+  double *d = nullptr, h[2] = {0, 0};
+  if (hipMalloc((void **)&d, 2 * sizeof(double)) != hipSuccess) return -1;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, 0);
+  if (t->K == 3)
+    hipLaunchKernelGGL((parts_kernel<3, 10>), dim3(1), dim3(WAVE), t->smem_bytes, 0, t->d_slot_meta,
+                       t->N, t->T, mode % 100, iters, d);
+  else
+    hipLaunchKernelGGL((parts_kernel<2, 6>), dim3(1), dim3(WAVE), t->smem_bytes, 0, t->d_slot_meta,
+                       t->N, t->T, mode % 100, iters, d);
+  (void)hipEventRecord(e1, 0);
+  (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipFree(d);
+  if (mode >= 100) return ms * 1e6 / iters;  // ns per iteration (wall)
+  return h[0];
 }
 
 // developer hook (not part of the ABI header): copy the GIK_DBG=4 dump to the host

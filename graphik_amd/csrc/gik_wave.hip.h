@@ -28,6 +28,29 @@
 namespace gik {
 
 constexpr int WAVE = 64;
+
+// build-time experiment switches (defaults = shipped configuration)
+#ifndef GIK_XROW
+#define GIK_XROW 0      // 0: v_readlane cross-row combine, 1: row_bcast15/31
+#endif
+#ifndef GIK_MERGE_R12
+#define GIK_MERGE_R12 1 // 1: curvature <delta,Hdelta> from the projection's reduction
+#endif
+#ifndef GIK_SPLIT_ACC
+#define GIK_SPLIT_ACC 1 // 1: two interleaved accumulators in ehess
+#endif
+#ifndef GIK_TREDUCE
+#define GIK_TREDUCE 1   // 1: MFMA (v_mfma_f64_4x4x4) wave reductions, 0: DPP butterfly
+#endif
+#ifndef GIK_FASTDIV
+#define GIK_FASTDIV 0   // 1: Newton reciprocal division for alpha/beta
+#endif
+#ifndef GIK_TREESUM
+#define GIK_TREESUM 1   // 1: pairwise tree for the slot sum of the Hessian-vector product
+#endif
+#ifndef GIK_BLOCKHV
+#define GIK_BLOCKHV 1   // 1: Hessian-vector product in block (graph-Laplacian) form
+#endif
 constexpr int TILE_ROWS = 33;  // 32 nodes max + one dump row for idle lanes
 
 // slot metadata word: [7:0] neighbour node j, [19:8] term index, [21:20] kind, [22] owner
@@ -55,10 +78,20 @@ __device__ inline double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_rows_f64(double v) {
+  // rows not selected by ROW_MASK receive 0.0 (`old`), selected rows the permuted source
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 // Sum NV independent per-lane values over the wavefront; result is wave-uniform (SGPR-backed).
 // Four DPP butterfly stages inside each row of 16 lanes (quad_perm xor1, xor2, half-mirror,
-// mirror), then the four row totals are read with v_readlane and added.  Fixed order =>
-// bit-reproducible run to run.
+// mirror) leave every lane with its row total; row_bcast15 folds row0 into row1 and row2 into
+// row3, row_bcast31 folds (row0+row1) into row3, whose lane 63 is read back with v_readlane.
+// Fixed order => bit-reproducible run to run.
 template <int NV>
 __device__ inline void wave_sum_n(double (&v)[NV]) {
 #pragma unroll
@@ -69,17 +102,111 @@ __device__ inline void wave_sum_n(double (&v)[NV]) {
   for (int q = 0; q < NV; ++q) v[q] += dpp_f64<0x141>(v[q]); // row_half_mirror
 #pragma unroll
   for (int q = 0; q < NV; ++q) v[q] += dpp_f64<0x140>(v[q]); // row_mirror
+#if GIK_XROW == 1
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] += dpp_rows_f64<0x142, 0xA>(v[q]);  // row_bcast15 -> rows 1,3
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] += dpp_rows_f64<0x143, 0xC>(v[q]);  // row_bcast31 -> rows 2,3
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] = readlane_f64(v[q], 63);
+#else
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const double r0 = readlane_f64(v[q], 0), r1 = readlane_f64(v[q], 16);
     const double r2 = readlane_f64(v[q], 32), r3 = readlane_f64(v[q], 48);
     v[q] = (r0 + r1) + (r2 + r3);
   }
+#endif
 }
+
+#if GIK_TREDUCE
+// ---- wave reductions on the matrix core ----------------------------------------------------
+// One wavefront issues a dependent fp64 VALU op only every ~28 cycles (measured), so the classic
+// 6-stage DPP butterfly (2 v_mov_dpp + 1 v_add_f64 per value and stage) costs ~350 cycles per
+// reduced value and made up 60 % of a tCG iteration.  v_mfma_f64_4x4x4 sums across lanes for
+// free: with B = 1 it returns  D[i][j] = sum_k A[i][k],  where on gfx950 (probed, see
+// tools/exp/mfma_layout.hip)  A[i][k] = lane (4b + i) + 16k  and  D[i][j] = lane (4b + j) + 16i
+// for the four 4-lane blocks b of a 16-lane row.  One instruction therefore adds the four rows
+// of a lane column, and feeding the result back in adds the four columns of a block: after two
+// instructions every lane holds the total of its block's 16 lanes (4 lanes x 4 rows).
+//   - one value : blocksum, then the four block totals are combined with three row_ror DPP moves.
+//   - up to four values: two transposing exchange stages first (partner = lane^8, then lane^4):
+//     a lane keeps one value of each pair and receives the partner's contribution to it, so
+//     afterwards block b of every row carries value perm(b); blocksum finishes all four at once.
+// Fixed data flow => bit-reproducible.  ~170 cycles for one value, ~300 for four.
+template <int CTRL, int BANK>
+__device__ inline double dpp_bank_f64(double old, double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(old), lo, CTRL, 0xf, BANK, false);
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, CTRL, 0xf, BANK, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double mfma_blocksum(double v) {
+  const double p = __builtin_amdgcn_mfma_f64_4x4x4f64(v, 1.0, 0.0, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(p, 1.0, 0.0, 0, 0, 0);
+}
+__device__ inline double lane_xor4(double x) {
+  const double t = dpp_bank_f64<0x104, 0x5>(x, x);  // row_shl:4 -> banks 0,2 read lane+4
+  return dpp_bank_f64<0x114, 0xA>(t, x);            // row_shr:4 -> banks 1,3 read lane-4
+}
+__device__ inline void wave_sum4(double &v0, double &v1, double &v2, double &v3) {
+  const int lane = threadIdx.x;
+  const bool h8 = lane & 8, h4 = lane & 4;
+  const double u0 = (h8 ? v1 : v0) + dpp_f64<0x128>(h8 ? v0 : v1);  // row_ror:8 == lane^8
+  const double u1 = (h8 ? v3 : v2) + dpp_f64<0x128>(h8 ? v2 : v3);
+  const double w = (h4 ? u1 : u0) + lane_xor4(h4 ? u0 : u1);
+  const double q = mfma_blocksum(w);
+  v0 = readlane_f64(q, 0);
+  v2 = readlane_f64(q, 4);
+  v1 = readlane_f64(q, 8);
+  v3 = readlane_f64(q, 12);
+}
+template <>
+__device__ inline void wave_sum_n<1>(double (&v)[1]) {
+  const double q = mfma_blocksum(v[0]);
+  const double t = (q + dpp_f64<0x124>(q)) + (dpp_f64<0x128>(q) + dpp_f64<0x12C>(q));
+  v[0] = readlane_f64(t, 0);
+}
+template <>
+__device__ inline void wave_sum_n<2>(double (&v)[2]) {
+  double z0 = 0.0, z1 = 0.0;
+  wave_sum4(v[0], v[1], z0, z1);
+}
+template <>
+__device__ inline void wave_sum_n<3>(double (&v)[3]) {
+  double z = 0.0;
+  wave_sum4(v[0], v[1], v[2], z);
+}
+template <>
+__device__ inline void wave_sum_n<4>(double (&v)[4]) {
+  wave_sum4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ inline void wave_sum_n<6>(double (&v)[6]) {
+  double z0 = 0.0, z1 = 0.0;
+  wave_sum4(v[0], v[1], v[2], v[3]);
+  wave_sum4(v[4], v[5], z0, z1);
+}
+#endif
+
 __device__ inline double wave_sum(double x) {
   double v[1] = {x};
   wave_sum_n<1>(v);
   return v[0];
+}
+
+// a / b with one Newton-refined reciprocal and a residual correction: <= 1 ulp from the IEEE
+// quotient at a third of the instruction count of the correctly rounded sequence
+__device__ inline double fdiv(double a, double b) {
+#if GIK_FASTDIV
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+#else
+  return a / b;
+#endif
 }
 
 // ---- solver parameters handed to the kernels ----------------------------------------------
@@ -123,9 +250,17 @@ struct WaveCtx {
   int own_off;             // this lane's node row in its own tile (double index)
   int nat_off;             // this lane's node row in tile 0 (natural component order)
   int rowoff[MAXDEG];      // neighbour rows in this lane's tile (double index)
+#if GIK_BLOCKHV
+  // Row of the 3x3 (2x2) Hessian block of slot s that belongs to this lane's component, rotated
+  // like the tiles:  bq[s][q] = 2 a y_c y_(c+q) + c_ij [q == 0].   bsum = sum_s bq[s].
+  double bq[MAXDEG][K];
+  double bsum[K];
+#else
   double ys[MAXDEG][K];    // sqrt(2 a_ij) * (Y_i - Y_j), rotated: [0] is this lane's component
   double cc[MAXDEG];       // c_ij = sum over active residuals of (d - target)
+#endif
   double pk[NC], pk2[NC], Pm[NC * NC];
+  double G2[NC * NC];      // <pk2_q, pk2_m>, constant during one tCG solve
 
   __device__ inline Row<K> read_row(int off) const {
     Row<K> r;
@@ -166,9 +301,14 @@ struct WaveCtx {
 #pragma unroll
     for (int s = 0; s < MAXDEG; ++s) {
       rowoff[s] = comp * TILE + meta_j(sh_meta[s * WAVE + lane]) * RS;
+#if GIK_BLOCKHV
+#pragma unroll
+      for (int q = 0; q < K; ++q) bq[s][q] = 0.0;
+#else
       cc[s] = 0.0;
 #pragma unroll
       for (int q = 0; q < K; ++q) ys[s][q] = 0.0;
+#endif
     }
   }
 
@@ -221,12 +361,28 @@ struct WaveCtx {
       const bool act = (kind == GIK_TERM_EQ) || (kind == GIK_TERM_LOWER && c0 < 0.0) ||
                        (kind == GIK_TERM_UPPER && c0 > 0.0);
       const double c = act ? c0 : 0.0;
+#if GIK_BLOCKHV
+      const double a2 = act ? 2.0 * y[0] : 0.0;          // 2 a y_c, a in {0,1}
+#pragma unroll
+      for (int q = 0; q < K; ++q) bq[s][q] = a2 * y[q];
+      bq[s][0] += c;
+#else
       const double sc = act ? 1.4142135623730951 : 0.0;  // sqrt(2 a), a in {0,1}
       cc[s] = c;
 #pragma unroll
       for (int q = 0; q < K; ++q) ys[s][q] = sc * y[q];
+#endif
       G = fma(c, y[0], G);
     }
+#if GIK_BLOCKHV
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      double t = 0.0;
+#pragma unroll
+      for (int s = 0; s < MAXDEG; ++s) t += bq[s][q];
+      bsum[q] = t;
+    }
+#endif
     return 2.0 * G;
   }
 
@@ -235,7 +391,38 @@ struct WaveCtx {
   __device__ inline double ehess(double W) {
     put(W);
     const Row<K> own = read_row(own_off);
-    double H = 0.0;
+#if GIK_BLOCKHV
+    // H_i = 2 sum_j B_ij (W_i - W_j) = 2 [ (sum_j B_ij) W_i - sum_j B_ij W_j ],  B_ij = 2a y y^T + c I
+    // -- the graph-Laplacian form the reference's dense closure uses
+    // (riemannian_solver.py:158-174: (A - diag(sum A)).dot(Z)); 3 fma per slot.
+    double t[MAXDEG + 1];
+    t[MAXDEG] = -(bsum[0] * own.v[0]);
+#pragma unroll
+    for (int q = 1; q < K; ++q) t[MAXDEG] = fma(-bsum[q], own.v[q], t[MAXDEG]);
+#pragma unroll
+    for (int s = 0; s < MAXDEG; ++s) {
+      const Row<K> r = read_row(rowoff[s]);
+      t[s] = bq[s][0] * r.v[0];
+#pragma unroll
+      for (int q = 1; q < K; ++q) t[s] = fma(bq[s][q], r.v[q], t[s]);
+    }
+#if GIK_TREESUM
+    // pairwise tree: a lone wavefront needs ~28 cycles per DEPENDENT fp64 add
+#pragma unroll
+    for (int w = 1; w <= MAXDEG; w *= 2) {
+#pragma unroll
+      for (int s = 0; s + w <= MAXDEG; s += 2 * w) t[s] += t[s + w];
+    }
+    return -2.0 * t[0];
+#else
+    double acc = t[MAXDEG];
+#pragma unroll
+    for (int s = 0; s < MAXDEG; ++s) acc += t[s];
+    return -2.0 * acc;
+#endif
+#else
+    // two interleaved accumulators (even / odd slots) halve the dependent fma chain
+    double H[2] = {0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < MAXDEG; ++s) {
       const Row<K> r = read_row(rowoff[s]);
@@ -245,9 +432,10 @@ struct WaveCtx {
       double sd = ys[s][0] * w[0];
 #pragma unroll
       for (int q = 1; q < K; ++q) sd = fma(ys[s][q], w[q], sd);
-      H = fma(sd, ys[s][0], fma(cc[s], w[0], H));
+      H[GIK_SPLIT_ACC ? (s & 1) : 0] = fma(sd, ys[s][0], fma(cc[s], w[0], H[GIK_SPLIT_ACC ? (s & 1) : 0]));
     }
-    return 2.0 * H;
+    return 2.0 * (H[0] + H[1]);
+#endif
   }
 
   // Factor the horizontal-space projector at the point whose rows are in the LDS tiles
@@ -276,6 +464,9 @@ struct WaveCtx {
       Pm[0] = c00 * idet; Pm[1] = c01 * idet; Pm[2] = c02 * idet;
       Pm[3] = c01 * idet; Pm[4] = c11 * idet; Pm[5] = c12 * idet;
       Pm[6] = c02 * idet; Pm[7] = c12 * idet; Pm[8] = c22 * idet;
+      // <pk_q, pk_m> summed over the lanes is M itself
+      G2[0] = a; G2[1] = b; G2[2] = c; G2[3] = b; G2[4] = d; G2[5] = e;
+      G2[6] = c; G2[7] = e; G2[8] = f;
       // vee(C) = sum_lanes pk * Z_lane ; (Y Omega)_lane = pk . o
       //   comp 0: (-y1, -y2, 0)   comp 1: (y0, 0, -y2)   comp 2: (0, y0, y1)
       const double am = active ? 1.0 : 0.0;
@@ -331,6 +522,7 @@ struct WaveCtx {
       pk[0] = am * (e1 * y0 - e0 * y1);
       pk2[0] = am * (e0 * (y0 * u0 + y1 * u2) + e1 * (y0 * u1 + y1 * u3));
       Pm[0] = 1.0;
+      G2[0] = wave_sum(pk2[0] * pk2[0]);
     }
   }
 
@@ -352,11 +544,51 @@ struct WaveCtx {
   }
 
   // rhess(x, delta) = proj(ehess(delta)) and the curvature <delta, rhess> (trust_region.py
-  // :497-500), evaluated literally: project first, then reduce delta * Hdelta.
-  __device__ inline double hess_proj_dot(double delta, double &d_Hd) {
-    const double Hd = proj(ehess(delta));
-    d_Hd = wave_sum(delta * Hd);
-    return Hd;
+  // :497-500) from ONE wave reduction.  With H = ehess(delta), v = <pk, H>, o = Pm v:
+  //     Hdelta = H - sum_m pk2_m o_m ,   <delta, Hdelta> = <delta, H> - sum_m o_m <delta, pk2_m>.
+  // s_m = <delta, pk2_m> only changes by wave-uniform scalars along the CG recurrences
+  // (delta' = -r' + beta delta, r' = r + alpha Hdelta), so the caller carries it:
+  //     rho_m += alpha * hd_pk_m ,  s_m = -rho_m + beta * s_m ,  rho_m(0) = <g, pk2_m> = -s_m(0)
+  // with hd_pk_m = <Hdelta, pk2_m> = <H, pk2_m> - sum_q o_q <pk2_q, pk2_m> returned here.
+  // Same inner product as the literal <delta, proj(ehess(delta))>, different summation order.
+  __device__ inline double hess_proj_dot(double delta, const double (&s_dpk)[NC], double &d_Hd,
+                                         double (&hd_pk)[NC]) {
+#if !GIK_MERGE_R12
+    {
+      const double Hd = proj(ehess(delta));
+      d_Hd = wave_sum(delta * Hd);
+#pragma unroll
+      for (int m = 0; m < NC; ++m) hd_pk[m] = 0.0;
+      return Hd;
+    }
+#endif
+    constexpr int NV = (K == 3) ? NC + 1 : NC + 2;  // k=2: pk2 != pk needs <pk2, H> as well
+    const double H = ehess(delta);
+    double v[NV];
+#pragma unroll
+    for (int m = 0; m < NC; ++m) v[m] = pk[m] * H;
+    v[NC] = delta * H;
+    if constexpr (K == 2) v[NC + 1] = pk2[0] * H;
+    wave_sum_n<NV>(v);
+    double out = H, dot = v[NC];
+    double o[NC];
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+      o[m] = 0.0;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) o[m] = fma(Pm[m * NC + q], v[q], o[m]);
+      out = fma(-pk2[m], o[m], out);
+      dot = fma(-o[m], s_dpk[m], dot);
+    }
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+      double t = (K == 3) ? v[m] : v[NC + 1];
+#pragma unroll
+      for (int q = 0; q < NC; ++q) t = fma(-o[q], G2[q * NC + m], t);
+      hd_pk[m] = t;
+    }
+    d_Hd = dot;
+    return out;
   }
 };
 
