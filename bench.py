@@ -37,9 +37,10 @@ def algorithmic_flops(N, k, T, n_inner, n_outer, n_accept):
     return n_inner * F_hv + n_outer * F_cost + n_accept * F_acc
 
 
-def algorithmic_bytes(N, k, n):
-    """goal in + Y out + q out + stats per solve."""
-    return 8 * (12 + N * k + n) + 32
+def algorithmic_bytes(N, k, T):
+    """HBM bytes the solve kernel must move per IK problem: T targets + Y_init in, Y_sol + stats
+    out (SURVEY 8(d) counts the pipeline-level 616 B/solve; the dominant kernel alone sees this)."""
+    return 8 * (T + 2 * N * k) + 32
 
 
 def main():
@@ -124,7 +125,7 @@ def main():
     acc_local = float(res["n_accept"].double().sum())
     flops = algorithmic_flops(N, k, T, inner_local, outer_local, acc_local)
     achieved_tf = flops / (kernel_ms * 1e-3) / 1e12
-    hbm_bytes = algorithmic_bytes(N, k, n) * B
+    hbm_bytes = algorithmic_bytes(N, k, T) * B
     value = world * B * args.steps / dt
     out = {
         "metric": "IK solves/sec (batched random goals)",
