@@ -26,7 +26,7 @@ class TemplateDesc(C.Structure):
         ("mingradnorm", C.c_double), ("maxiter", C.c_int32), ("maxinner", C.c_int32),
         ("mininner", C.c_int32), ("theta", C.c_double), ("kappa", C.c_double),
         ("rho_prime", C.c_double), ("rho_regularization", C.c_double),
-        ("planar_proj_exact", C.c_int32),
+        ("planar_proj_exact", C.c_int32), ("force_block_path", C.c_int32),
     ]
 
 

@@ -1,0 +1,329 @@
+// graphik_amd/csrc/gik_block.hip.h -- workgroup-per-IK-problem context for graphs that do not fit
+// one wavefront (N*k > 64): e.g. UR10 + table_environment() with N = 116 nodes and 5612 residual
+// terms (BASELINE configs[2]; every obstacle is a free point tied to all anchors).
+//
+// 512 threads, four per node ("parts" = one DPP quad).  Thread (node i, part p < k) owns the
+// unknown (i, p); all four parts of a node share the node's residual terms (a quarter each).  A
+// node with ~100 neighbours cannot cache per-slot Hessian blocks in registers, so the
+// Hessian-vector product recomputes y = Y_i - Y_j, d, c from the point rows kept in LDS; each term
+// is evaluated from both endpoints (owner-computes: no scatter, no atomics, fixed summation
+// order), the four partial 3-vectors of a node are combined with two quad_perm DPP stages.
+// Reductions: per-wave MFMA reduction, then eight wave totals through a double-buffered LDS
+// scratch (one barrier per reduction).  The solver logic is the shared rtr_solve_one<>.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gik_wave.hip.h"
+
+namespace gik {
+
+constexpr int BLOCK_NT = 512;
+constexpr int BLOCK_WAVES = BLOCK_NT / WAVE;
+constexpr int BLOCK_MAXN = BLOCK_NT / 4;  // 128 nodes
+
+template <int K>
+struct BlockCtx {
+  static constexpr int NC = (K == 3) ? 3 : 1;
+  static constexpr int RS = 4;  // LDS row stride (doubles): 32-byte rows
+
+  int tid, lane, wave, node, part, N, SL;
+  bool active;       // owns an unknown: node < N && part < K
+  double *sh_Y;      // [128][4] accepted point
+  double *sh_P;      // [128][4] proposal (cost) / point being committed
+  double *sh_W;      // [128][4] direction being differentiated
+  const double *sh_tgt;
+  const uint32_t *sh_slots;  // [SL][512]
+  double *sh_red;            // [2][8][BLOCK_WAVES]
+  int red_buf;
+  double pk[NC], pk2[NC], Pm[NC * NC], G2[NC * NC];
+
+  __host__ __device__ static constexpr size_t lds_bytes(int T, int SL) {
+    return sizeof(double) * ((size_t)3 * BLOCK_MAXN * RS + (size_t)((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES) +
+           sizeof(uint32_t) * (size_t)SL * BLOCK_NT;
+  }
+
+  __device__ inline bool lead() const { return tid == 0; }
+
+  __device__ inline void init(int N_, int SL_, double *base, const uint32_t *slots_lds, int T) {
+    tid = threadIdx.x;
+    lane = tid & 63;
+    wave = tid >> 6;
+    node = tid >> 2;
+    part = tid & 3;
+    N = N_;
+    SL = SL_;
+    active = node < N && part < K;
+    sh_Y = base;
+    sh_P = sh_Y + BLOCK_MAXN * RS;
+    sh_W = sh_P + BLOCK_MAXN * RS;
+    double *tg = sh_W + BLOCK_MAXN * RS;
+    sh_tgt = tg;
+    sh_red = tg + ((T + 1) & ~1);
+    sh_slots = slots_lds;
+    red_buf = 0;
+  }
+
+  template <int NV>
+  __device__ inline void sum_n(double (&v)[NV]) {
+    static_assert(NV <= 8, "reduction scratch holds 8 values");
+    wave_sum_n<NV>(v);  // wave totals, uniform within the wave
+    double *buf = sh_red + red_buf * 8 * BLOCK_WAVES;
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) buf[q * BLOCK_WAVES + wave] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const double *r = buf + q * BLOCK_WAVES;
+      v[q] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    }
+    red_buf ^= 1;  // the next reduction writes the other buffer: one barrier per reduction
+  }
+  __device__ inline double sum1(double x) {
+    double v[1] = {x};
+    sum_n<1>(v);
+    return v[0];
+  }
+
+  __device__ inline void row(const double *M, int r, double (&o)[K]) const {
+    const double2 a = *reinterpret_cast<const double2 *>(M + r * RS);
+    o[0] = a.x;
+    o[1] = a.y;
+    if constexpr (K == 3) o[2] = M[r * RS + 2];
+  }
+
+  // sum the four parts of a node (one DPP quad) and return entry `part` of the result
+  __device__ inline double quad_pick(double (&acc)[K]) const {
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc[q] += dpp_f64<0xB1>(acc[q]);
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc[q] += dpp_f64<0x4E>(acc[q]);
+    if constexpr (K == 3)
+      return part == 0 ? acc[0] : (part == 1 ? acc[1] : acc[2]);
+    else
+      return part == 0 ? acc[0] : acc[1];
+  }
+
+  // f(Yv) (lcost / jcost, costs.py:80-93, 8-16); leaves Yv in sh_P
+  __device__ inline double cost(double Yv) {
+    if (active) sh_P[node * RS + part] = Yv;
+    __syncthreads();
+    double own[K];
+    row(sh_P, node < N ? node : 0, own);
+    double f = 0.0;
+    for (int s = 0; s < SL; ++s) {
+      const uint32_t m = sh_slots[s * BLOCK_NT + tid];
+      double r[K];
+      row(sh_P, meta_j(m), r);
+      double d = 0.0;
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        const double y = own[q] - r[q];
+        d = fma(y, y, d);
+      }
+      const int kind = meta_kind(m);
+      const double u = sh_tgt[meta_term(m)] - d;
+      const double wp = (meta_owner(m) && (kind == GIK_TERM_EQ || kind == GIK_TERM_LOWER)) ? 1.0 : 0.0;
+      const double wn = (meta_owner(m) && (kind == GIK_TERM_EQ || kind == GIK_TERM_UPPER)) ? 1.0 : 0.0;
+      const double pp = fmax(u, 0.0), nn = fmax(-u, 0.0);
+      f = fma(wp * pp, pp, f);
+      f = fma(wn * nn, nn, f);
+    }
+    return sum1(f);
+  }
+
+  // accept the point in sh_P: copy it to sh_Y and return this thread's egrad entry
+  __device__ inline double commit() {
+    double own[K];
+    row(sh_P, node < N ? node : 0, own);
+    double acc[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc[q] = 0.0;
+    for (int s = 0; s < SL; ++s) {
+      const uint32_t m = sh_slots[s * BLOCK_NT + tid];
+      double r[K], y[K];
+      row(sh_P, meta_j(m), r);
+      double d = 0.0;
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        y[q] = own[q] - r[q];
+        d = fma(y[q], y[q], d);
+      }
+      const int kind = meta_kind(m);
+      const double c0 = d - sh_tgt[meta_term(m)];
+      const bool act = (kind == GIK_TERM_EQ) || (kind == GIK_TERM_LOWER && c0 < 0.0) ||
+                       (kind == GIK_TERM_UPPER && c0 > 0.0);
+      const double c = act ? c0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < K; ++q) acc[q] = fma(c, y[q], acc[q]);
+    }
+    const double G = 2.0 * quad_pick(acc);
+    if (active) sh_Y[node * RS + part] = sh_P[node * RS + part];
+    __syncthreads();
+    return active ? G : 0.0;
+  }
+
+  // ehess(Y, W) (lhess / jhess, costs.py:175-207, 39-58) at the committed point sh_Y
+  __device__ inline double ehess(double W) {
+    if (active) sh_W[node * RS + part] = W;
+    __syncthreads();
+    const int me = node < N ? node : 0;
+    double yi[K], wi[K];
+    row(sh_Y, me, yi);
+    row(sh_W, me, wi);
+    double acc[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc[q] = 0.0;
+    for (int s = 0; s < SL; ++s) {
+      const uint32_t m = sh_slots[s * BLOCK_NT + tid];
+      const int j = meta_j(m);
+      double yj[K], wj[K], y[K], w[K];
+      row(sh_Y, j, yj);
+      row(sh_W, j, wj);
+      double d = 0.0, sd = 0.0;
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        y[q] = yi[q] - yj[q];
+        w[q] = wi[q] - wj[q];
+        d = fma(y[q], y[q], d);
+        sd = fma(y[q], w[q], sd);
+      }
+      const int kind = meta_kind(m);
+      const double c0 = d - sh_tgt[meta_term(m)];
+      const bool act = (kind == GIK_TERM_EQ) || (kind == GIK_TERM_LOWER && c0 < 0.0) ||
+                       (kind == GIK_TERM_UPPER && c0 > 0.0);
+      const double c = act ? c0 : 0.0;
+      const double a2s = act ? 2.0 * sd : 0.0;
+#pragma unroll
+      for (int q = 0; q < K; ++q) acc[q] = fma(a2s, y[q], fma(c, w[q], acc[q]));
+    }
+    const double H = 2.0 * quad_pick(acc);
+    return active ? H : 0.0;
+  }
+
+  // horizontal-space projector at the committed point (same algebra as WaveCtx::proj_setup)
+  __device__ inline void proj_setup(int planar_proj_exact) {
+    double own[K];
+    row(sh_Y, node < N ? node : 0, own);
+    const double lm = (node < N && part == 0) ? 1.0 : 0.0;
+    const double am = active ? 1.0 : 0.0;
+    if constexpr (K == 3) {
+      const double y0 = own[0], y1 = own[1], y2 = own[2];
+      double x[6] = {lm * y0 * y0, lm * y0 * y1, lm * y0 * y2, lm * y1 * y1, lm * y1 * y2,
+                     lm * y2 * y2};
+      sum_n<6>(x);
+      const double X00 = x[0], X01 = x[1], X02 = x[2], X11 = x[3], X12 = x[4], X22 = x[5];
+      const double a = X00 + X11, b = X12, c = -X02, d = X00 + X22, e = X01, f = X11 + X22;
+      const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+      const double c11 = a * f - c * c, c12 = b * c - a * e, c22 = a * d - b * b;
+      const double idet = 1.0 / (a * c00 + b * c01 + c * c02);
+      Pm[0] = c00 * idet; Pm[1] = c01 * idet; Pm[2] = c02 * idet;
+      Pm[3] = c01 * idet; Pm[4] = c11 * idet; Pm[5] = c12 * idet;
+      Pm[6] = c02 * idet; Pm[7] = c12 * idet; Pm[8] = c22 * idet;
+      G2[0] = a; G2[1] = b; G2[2] = c; G2[3] = b; G2[4] = d; G2[5] = e;
+      G2[6] = c; G2[7] = e; G2[8] = f;
+      const double e0 = part == 0 ? 1.0 : 0.0, e1 = part == 1 ? 1.0 : 0.0,
+                   e2 = part == 2 ? 1.0 : 0.0;
+      pk[0] = pk2[0] = am * (e1 * y0 - e0 * y1);
+      pk[1] = pk2[1] = am * (e2 * y0 - e0 * y2);
+      pk[2] = pk2[2] = am * (e2 * y1 - e1 * y2);
+    } else {
+      const double y0 = own[0], y1 = own[1];
+      double x[3] = {lm * y0 * y0, lm * y0 * y1, lm * y1 * y1};
+      sum_n<3>(x);
+      const double X00 = x[0], X01 = x[1], X11 = x[2];
+      double u0, u1, u2, u3;
+      if (planar_proj_exact) {
+        const double it = 1.0 / (X00 + X11);
+        u0 = 0.0; u1 = it; u2 = -it; u3 = 0.0;
+      } else {
+        double A[4][5] = {{X00 + X00, X01, X01, 0.0, 0.0},
+                          {X01, X01 + X00, 0.0, X01, 1.0},
+                          {X01, 0.0, X00 + X11, X01, -1.0},
+                          {0.0, X01, X01, X11 + X11, 0.0}};
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+#pragma unroll
+          for (int r = col + 1; r < 4; ++r) {
+            const bool sw = fabs(A[r][col]) > fabs(A[col][col]);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+              const double p = A[col][t], q = A[r][t];
+              A[col][t] = sw ? q : p;
+              A[r][t] = sw ? p : q;
+            }
+          }
+          const double ip = 1.0 / A[col][col];
+#pragma unroll
+          for (int r = col + 1; r < 4; ++r) {
+            const double fct = A[r][col] * ip;
+#pragma unroll
+            for (int t = col; t < 5; ++t) A[r][t] = fma(-fct, A[col][t], A[r][t]);
+          }
+        }
+        u3 = A[3][4] / A[3][3];
+        u2 = (A[2][4] - A[2][3] * u3) / A[2][2];
+        u1 = (A[1][4] - A[1][2] * u2 - A[1][3] * u3) / A[1][1];
+        u0 = (A[0][4] - A[0][1] * u1 - A[0][2] * u2 - A[0][3] * u3) / A[0][0];
+      }
+      const double e0 = part == 0 ? 1.0 : 0.0, e1 = 1.0 - e0;
+      pk[0] = am * (e1 * y0 - e0 * y1);
+      pk2[0] = am * (e0 * (y0 * u0 + y1 * u2) + e1 * (y0 * u1 + y1 * u3));
+      Pm[0] = 1.0;
+      G2[0] = sum1(pk2[0] * pk2[0]);
+    }
+  }
+
+  __device__ inline double proj(double Z) {
+    double v[NC];
+#pragma unroll
+    for (int m = 0; m < NC; ++m) v[m] = pk[m] * Z;
+    sum_n<NC>(v);
+    double out = Z;
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+      double o = 0.0;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) o = fma(Pm[m * NC + q], v[q], o);
+      out = fma(-pk2[m], o, out);
+    }
+    return out;
+  }
+
+  // same contract as WaveCtx::hess_proj_dot
+  __device__ inline double hess_proj_dot(double delta, const double (&s_dpk)[NC], double &d_Hd,
+                                         double (&hd_pk)[NC]) {
+    constexpr int NV = (K == 3) ? NC + 1 : NC + 2;
+    const double H = ehess(delta);
+    double v[NV];
+#pragma unroll
+    for (int m = 0; m < NC; ++m) v[m] = pk[m] * H;
+    v[NC] = delta * H;
+    if constexpr (K == 2) v[NC + 1] = pk2[0] * H;
+    sum_n<NV>(v);
+    double out = H, dot = v[NC];
+    double o[NC];
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+      o[m] = 0.0;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) o[m] = fma(Pm[m * NC + q], v[q], o[m]);
+      out = fma(-pk2[m], o[m], out);
+      dot = fma(-o[m], s_dpk[m], dot);
+    }
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+      double t = (K == 3) ? v[m] : v[NC + 1];
+#pragma unroll
+      for (int q = 0; q < NC; ++q) t = fma(-o[q], G2[q * NC + m], t);
+      hd_pk[m] = t;
+    }
+    d_Hd = dot;
+    return out;
+  }
+};
+
+}  // namespace gik

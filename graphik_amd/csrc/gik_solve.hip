@@ -16,7 +16,9 @@
 #include <string>
 #include <vector>
 
+#include "gik_block.hip.h"
 #include "gik_prep.hip.h"
+#include "gik_rtr.hip.h"
 #include "gik_wave.hip.h"
 #include "graphik_amd.h"
 
@@ -39,11 +41,6 @@ struct SolveArgs {
   Params p;
 };
 
-// Branch conditions on solver scalars are identical in all 64 lanes; routing them through a
-// ballot makes that explicit (the predicate lands in an SGPR pair, the branch is scalar) so the
-// structurizer never builds exec-masked loops around the wave-level reductions.
-#define UNI(cond) (__builtin_amdgcn_ballot_w64(cond) != 0ull)
-
 // Stage the launch-invariant slot table into LDS and zero the gather tiles (idle lanes and
 // padding slots read the never-written dump row, which must hold finite zeros).
 template <typename Ctx>
@@ -52,19 +49,6 @@ __device__ inline void stage_lds(double *tiles, uint32_t *meta, const uint32_t *
   for (int t = lane; t < ktiles * Ctx::TILE; t += WAVE) tiles[t] = 0.0;
   for (int s = 0; s < maxdeg; ++s) meta[s * WAVE + lane] = g_meta[s * WAVE + lane];
   __builtin_amdgcn_wave_barrier();
-}
-
-// ||g||_F together with <g, pk2_m> in one reduction
-template <typename Ctx>
-__device__ inline double grad_norm_and_rho(const Ctx &cx, double g, double (&rho0)[Ctx::NC]) {
-  double v[Ctx::NC + 1];
-  v[0] = g * g;
-#pragma unroll
-  for (int m = 0; m < Ctx::NC; ++m) v[m + 1] = g * cx.pk2[m];
-  wave_sum_n<Ctx::NC + 1>(v);
-#pragma unroll
-  for (int m = 0; m < Ctx::NC; ++m) rho0[m] = v[m + 1];
-  return sqrt(v[0]);
 }
 
 // Persistent kernel: grid = (resident waves), each wavefront claims IK problems from a global
@@ -85,8 +69,6 @@ __global__ void __launch_bounds__(WAVE) rtr_wave_kernel(SolveArgs a) {
   Ctx cx;
   cx.init(lane, a.N, sh_tiles, sh_tgt, sh_meta);
   const Params &p = a.p;
-  const double Delta_bar = 10.0 + K;  // typicaldist (fixed_rank_psd_sym.py:71-73)
-
   int pass = 0;
   for (;;) {
     int b = 0;
@@ -103,142 +85,11 @@ __global__ void __launch_bounds__(WAVE) rtr_wave_kernel(SolveArgs a) {
     __builtin_amdgcn_wave_barrier();
     double x = cx.active ? a.Y_init[(size_t)b * NK + lane] : 0.0;
 
-    double Delta = Delta_bar / 8.0;         // trust_region.py:134-135,164
-    double fx = cx.cost(x);                 // :159
-    double g = cx.commit();                 // :160  (also loads the slot constants at x)
-    cx.proj_setup(p.planar_proj_exact);
-    // ||grad|| (:161) and rho0_m = <grad, pk2_m> (start values of the tCG recurrences)
-    double rho0[Ctx::NC];
-    double norm_grad = grad_norm_and_rho(cx, g, rho0);
-    int kiter = 0, inner_total = 0, n_accept = 0, stop = 1;
-    bool bad = UNI(!(fx == fx) || !(norm_grad == norm_grad));
-    if (a.dbg & 2) bad = true;
-
-    while (!bad) {
-      // -------------- _truncated_conjugate_gradient (trust_region.py:436-599) -------------
-      double eta = 0.0, Heta = 0.0, r = g;       // :444-448
-      double e_Pe = 0.0;
-      double r_r = wave_sum(r * r);              // :455
-      const double norm_r0 = sqrt(r_r);
-      const double nr0_theta = (p.theta == 1.0) ? norm_r0 : pow(norm_r0, p.theta);
-      const double target = norm_r0 * fmin(nr0_theta, p.kappa);  // rhs of :572
-      const double target2 = target * target;
-      double z_r = r_r, d_Pd = r_r;              // :464-466 (precon = identity)
-      double delta = -r;                         // :469
-      double e_Pd = 0.0, model_value = 0.0;      // :471,485
-      int stop_tCG = TCG_MAX_INNER_ITER;         // :491
-      double rho_pk[Ctx::NC], s_pk[Ctx::NC], hd_pk[Ctx::NC];  // <r,pk2>, <delta,pk2>, <Hdelta,pk2>
-#pragma unroll
-      for (int m = 0; m < Ctx::NC; ++m) {
-        rho_pk[m] = rho0[m];
-        s_pk[m] = -rho0[m];
-      }
-      int j = 0;
-      for (j = 0; j < p.maxinner; ++j) {         // :495
-        double d_Hd;
-        const double Hdelta = cx.hess_proj_dot(delta, s_pk, d_Hd, hd_pk);  // :497-500
-        if (UNI(!(d_Hd == d_Hd))) { bad = true; break; }
-        const double alpha = fdiv(z_r, d_Hd);             // :503
-        const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;  // :506
-        if (UNI(d_Hd <= 0.0 || e_Pe_new >= Delta * Delta)) {   // :509
-          const double tau =
-              (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta * Delta - e_Pe))) / d_Pd;  // :514
-          eta = eta + tau * delta;                        // :516
-          Heta = Heta + tau * Hdelta;                     // :521
-          stop_tCG = (d_Hd <= 0.0) ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;  // :531-534
-          break;
-        }
-        if ((a.dbg & 4) && b == 0 && lane == 0 && a.dbg_buf && kiter < 64 && j < 128) {
-          double *q = a.dbg_buf + ((size_t)kiter * 128 + j) * 4;
-          q[0] = r_r; q[1] = d_Hd; q[2] = alpha; q[3] = model_value;
-        }
-        e_Pe = e_Pe_new;                                  // :537
-        const double new_eta = eta + alpha * delta;       // :538
-        const double new_Heta = Heta + alpha * Hdelta;    // :542
-        const double new_r = r + alpha * Hdelta;          // :561 (speculative; same value)
-        double m[3] = {new_eta * g, new_eta * new_Heta, new_r * new_r};
-        wave_sum_n<3>(m);
-        const double new_model_value = m[0] + 0.5 * m[1]; // :551
-        if (UNI(new_model_value >= model_value)) {        // :552
-          stop_tCG = TCG_MODEL_INCREASED;
-          break;
-        }
-        eta = new_eta;                                    // :556-558
-        Heta = new_Heta;
-        model_value = new_model_value;
-        r = new_r;                                        // :561
-        r_r = m[2];                                       // :564
-        // :572  norm_r <= norm_r0*min(norm_r0^theta, kappa), compared on the squares
-        if (UNI(j >= p.mininner && r_r <= target2)) {
-          stop_tCG = (p.kappa < nr0_theta) ? TCG_REACHED_TARGET_LINEAR
-                                           : TCG_REACHED_TARGET_SUPERLINEAR;
-          break;
-        }
-        const double zold_rold = z_r;                     // :587
-        z_r = r_r;                                        // :589
-        const double beta = fdiv(z_r, zold_rold);         // :592
-        delta = -r + beta * delta;                        // :593
-#pragma unroll
-        for (int m = 0; m < Ctx::NC; ++m) {               // the same two updates seen through pk2
-          rho_pk[m] = fma(alpha, hd_pk[m], rho_pk[m]);
-          s_pk[m] = fma(beta, s_pk[m], -rho_pk[m]);
-        }
-        e_Pd = beta * (e_Pd + alpha * d_Pd);              // :596
-        d_Pd = z_r + beta * beta * d_Pd;                  // :597
-      }
-      if (bad) break;
-      if (j >= p.maxinner) j = p.maxinner - 1;  // Python leaves j at the last index
-      inner_total += j + 1;
-
-      // -------------- outer iteration (trust_region.py:248-422) ---------------------------
-      if (a.has_trace && kiter < a.trace.cap && lane == 0) {
-        const size_t q = (size_t)b * a.trace.cap + kiter;
-        a.trace.d_Delta[q] = Delta;
-        a.trace.d_numit[q] = j;
-        a.trace.d_stop[q] = stop_tCG;
-        a.trace.d_f_before[q] = fx;
-      }
-      const double x_prop = x + eta;                     // :248 retr
-      const double fx_prop = cx.cost(x_prop);            // :251
-      double rhonum = fx - fx_prop;                      // :255
-      double gd[2] = {g * eta, eta * Heta};
-      wave_sum_n<2>(gd);
-      double rhoden = -gd[0] - 0.5 * gd[1];              // :256
-      const double rho_reg =
-          fmax(1.0, fabs(fx)) * 2.220446049250313e-16 * p.rho_regularization;  // :287
-      rhonum += rho_reg;                                 // :288
-      rhoden += rho_reg;                                 // :289
-      const bool model_decreased = rhoden >= 0.0;        // :311
-      const double rho = rhonum / rhoden;                // :317
-      if (rho < 0.25 || !model_decreased || !(rho == rho)) {  // :336
-        Delta = Delta / 4.0;                             // :338
-      } else if (rho > 0.75 &&
-                 (stop_tCG == TCG_NEGATIVE_CURVATURE || stop_tCG == TCG_EXCEEDED_TR)) {
-        Delta = fmin(2.0 * Delta, Delta_bar);            // :357-361
-      }
-      int accept = 0;
-      if (UNI(model_decreased && rho > p.rho_prime)) {   // :382
-        accept = 1;
-        ++n_accept;
-        x = x_prop;                                      // :385
-        fx = fx_prop;                                    // :386
-        g = cx.commit();                                 // :387 (rows of x_prop are in LDS)
-        cx.proj_setup(p.planar_proj_exact);
-        norm_grad = grad_norm_and_rho(cx, g, rho0);      // :388
-      }
-      if (a.has_trace && kiter < a.trace.cap && lane == 0) {
-        const size_t q = (size_t)b * a.trace.cap + kiter;
-        a.trace.d_gradnorm_after[q] = norm_grad;
-        a.trace.d_accept[q] = accept;
-      }
-      kiter = kiter + 1;                                 // :394
-      // :414-416 stopping criterion (pymanopt 0.2.5 order: maxiter before gradnorm; the
-      // wall-clock maxtime test is not reproduced -- it is non-deterministic)
-      if (kiter >= p.maxiter) { stop = 1; break; }
-      if (UNI(norm_grad < p.mingradnorm)) { stop = 0; break; }
-      if (UNI(!(norm_grad == norm_grad) || !(fx == fx))) { bad = true; break; }
-    }
-    if (bad) stop = 2;
+    RtrOut ro;
+    rtr_solve_one<K>(cx, p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro);
+    const double fx = ro.f, norm_grad = ro.gradnorm;
+    const int kiter = ro.iterations, inner_total = ro.inner_total, stop = ro.stop,
+              n_accept = ro.n_accept;
 
     if (cx.active) a.Y_out[(size_t)b * NK + lane] = x;
     if (lane == 0) {
@@ -302,6 +153,85 @@ __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
     res = cx.proj(w);
   }
   if (cx.active) a.out[(size_t)b * NK + lane] = res;
+}
+
+// ------------------------------------------------------------------------------------------
+// workgroup-per-problem variants (graphs with N*k > 64)
+template <int K>
+__device__ inline uint32_t *block_stage(BlockCtx<K> &cx, double *smem, const uint32_t *g_slots, int N,
+                                        int T, int SL) {
+  const int tid = threadIdx.x;
+  for (int t = tid; t < 3 * BLOCK_MAXN * BlockCtx<K>::RS; t += BLOCK_NT) smem[t] = 0.0;
+  double *tg = smem + 3 * BLOCK_MAXN * BlockCtx<K>::RS;
+  uint32_t *slots = reinterpret_cast<uint32_t *>(tg + ((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES);
+  for (int s = 0; s < SL; ++s) slots[s * BLOCK_NT + tid] = g_slots[s * BLOCK_NT + tid];
+  cx.init(N, SL, smem, slots, T);
+  __syncthreads();
+  return slots;
+}
+
+template <int K>
+__global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL) {
+  extern __shared__ double smem[];
+  __shared__ int sh_b;
+  const int tid = threadIdx.x;
+  const int NK = a.N * K;
+  BlockCtx<K> cx;
+  block_stage<K>(cx, smem, a.slot_meta, a.N, a.T, SL);
+  double *sh_tgt = smem + 3 * BLOCK_MAXN * BlockCtx<K>::RS;
+  for (;;) {
+    if (tid == 0) sh_b = (int)atomicAdd(a.work_counter, 1u);
+    __syncthreads();
+    const int b = sh_b;
+    __syncthreads();
+    if (UNI(b >= a.B)) break;
+    for (int t = tid; t < a.T; t += BLOCK_NT) sh_tgt[t] = a.targets[(size_t)b * a.T + t];
+    __syncthreads();
+    double x = cx.active ? a.Y_init[(size_t)b * NK + cx.node * K + cx.part] : 0.0;
+    RtrOut ro;
+    rtr_solve_one<K>(cx, a.p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro);
+    if (cx.active) a.Y_out[(size_t)b * NK + cx.node * K + cx.part] = x;
+    if (tid == 0) {
+      gik_stats s;
+      s.f = ro.f;
+      s.gradnorm = ro.gradnorm;
+      s.iterations = ro.iterations;
+      s.inner_total = ro.inner_total;
+      s.stop = ro.stop;
+      s.n_accept = ro.n_accept;
+      a.stats[b] = s;
+    }
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(BLOCK_NT) kat_block_kernel(KatArgs a, int SL) {
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const int NK = a.N * K;
+  BlockCtx<K> cx;
+  block_stage<K>(cx, smem, a.slot_meta, a.N, a.T, SL);
+  double *sh_tgt = smem + 3 * BLOCK_MAXN * BlockCtx<K>::RS;
+  for (int t = tid; t < a.T; t += BLOCK_NT)
+    sh_tgt[t] = a.targets ? a.targets[(size_t)b * a.T + t] : 0.0;
+  __syncthreads();
+  const size_t at = (size_t)b * NK + cx.node * K + cx.part;
+  const double y = cx.active ? a.Y[at] : 0.0;
+  const double w = (a.W && cx.active) ? a.W[at] : 0.0;
+  const double f = cx.cost(y);
+  if (a.mode == 0) {
+    if (tid == 0) a.out[b] = f;
+    return;
+  }
+  double res = cx.commit();
+  if (a.mode == 2) {
+    res = cx.ehess(w);
+  } else if (a.mode == 3) {
+    cx.proj_setup(a.planar_proj_exact);
+    res = cx.proj(w);
+  }
+  if (cx.active) a.out[at] = res;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -419,6 +349,8 @@ struct gik_template {
   int n_cu;
   int waves_per_cu;  // resident solve wavefronts per CU (from the occupancy query)
   size_t smem_bytes;
+  bool is_block;  // workgroup-per-problem path
+  int SL;         // slots per thread on the block path
   // device pre/post-processing (gik_pipeline_attach)
   bool has_pipe;
   gik::PipeConst pc;
@@ -463,6 +395,7 @@ void gik_default_params(gik_template_desc *d) {
   d->rho_prime = 0.1;           // trust_region.py:90
   d->rho_regularization = 1e3;  // trust_region.py:92
   d->planar_proj_exact = 0;
+  d->force_block_path = 0;
 }
 
 int gik_template_create(const gik_template_desc *d, gik_template **out) {
@@ -470,9 +403,9 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   if (!d || !out) return fail("null argument");
   if (d->abi_version != GIK_ABI_VERSION) return fail("ABI version mismatch");
   if (d->k != 2 && d->k != 3) return fail("k must be 2 or 3");
-  if (d->N < 2 || d->N * d->k > WAVE || d->N > 32)
-    return fail("wave-per-problem path needs N*k <= 64 (use the block path for larger graphs)");
-  if (d->n_terms < 1 || d->n_terms > 4095) return fail("n_terms out of range");
+  const bool is_block = d->N * d->k > WAVE || d->N > 32 || d->force_block_path != 0;
+  if (d->N < 2 || d->N > BLOCK_MAXN) return fail("N must be in [2, 128]");
+  if (d->n_terms < 1 || d->n_terms > 65535) return fail("n_terms out of range");
   const int N = d->N, T = d->n_terms;
   // per-node slot lists, in (neighbour, kind) order == the order the reference's edge loop
   // (row-major upper-triangle index pairs) accumulates into each row
@@ -494,11 +427,32 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
     maxdeg = std::max(maxdeg, (int)ents[i].size());
   }
   const Variant *var = nullptr;
+  int MD = 0, SL = 0;
+  std::vector<uint32_t> meta;
+  if (is_block) {
+    // four threads per node, a contiguous quarter of the node's terms each
+    for (int i = 0; i < N; ++i) SL = std::max(SL, ((int)ents[i].size() + 3) / 4);
+    meta.assign((size_t)SL * BLOCK_NT, 0);
+    for (int tid = 0; tid < BLOCK_NT; ++tid) {
+      const int node = tid >> 2, part = tid & 3;
+      const int deg = node < N ? (int)ents[node].size() : 0;
+      const int L = (deg + 3) / 4;
+      for (int s = 0; s < SL; ++s) {
+        uint32_t m = meta_pack(node < N ? node : 0, 0, 0, 0);
+        const int e = part * L + s;
+        if (s < L && e < deg) {
+          const Ent &en = ents[node][e];
+          m = meta_pack(en.j, en.term, en.kind, en.owner);
+        }
+        meta[(size_t)s * BLOCK_NT + tid] = m;
+      }
+    }
+  } else {
   for (const Variant &v : kVariants)
     if (v.K == d->k && v.maxdeg >= maxdeg && (!var || v.maxdeg < var->maxdeg)) var = &v;
   if (!var) return fail("node degree exceeds the largest compiled slot count");
-  const int MD = var->maxdeg;
-  std::vector<uint32_t> meta((size_t)MD * WAVE, 0);
+  MD = var->maxdeg;
+  meta.assign((size_t)MD * WAVE, 0);
   for (int lane = 0; lane < WAVE; ++lane) {
     const bool active = lane < N * d->k;
     const int node = active ? lane / d->k : 0;
@@ -513,11 +467,14 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
       meta[(size_t)s * WAVE + lane] = m;
     }
   }
+  }
   gik_template *t = new gik_template();
+  t->is_block = is_block;
+  t->SL = SL;
   t->N = N;
   t->K = d->k;
   t->T = T;
-  t->maxdeg = MD;
+  t->maxdeg = is_block ? SL : MD;
   t->variant = var;
   t->p.mingradnorm = d->mingradnorm;
   t->p.theta = d->theta;
@@ -532,7 +489,30 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   t->d_counters = nullptr;
   t->next_counter = 0;
   t->has_pipe = false;
-  t->smem_bytes = var->lds(T);
+  t->smem_bytes = is_block ? (d->k == 3 ? BlockCtx<3>::lds_bytes(T, SL) : BlockCtx<2>::lds_bytes(T, SL))
+                           : var->lds(T);
+  if (is_block && t->smem_bytes > 160 * 1024) {
+    delete t;
+    return fail("graph too large for the LDS-resident block path");
+  }
+  const void *solve_kernel =
+      is_block ? (d->k == 3 ? (const void *)rtr_block_kernel<3> : (const void *)rtr_block_kernel<2>)
+               : (const void *)var->solve;
+  if (is_block && t->smem_bytes > 48 * 1024) {
+    // more than the default dynamic-LDS allowance: opt in for exactly what this template needs
+    const void *fns[2] = {solve_kernel, d->k == 3 ? (const void *)kat_block_kernel<3>
+                                                  : (const void *)kat_block_kernel<2>};
+    for (const void *fn : fns) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)t->smem_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        const std::string msg =
+            "cannot reserve " + std::to_string(t->smem_bytes) + " bytes of LDS per workgroup";
+        delete t;
+        return fail(msg);
+      }
+    }
+  }
   hipDeviceProp_t prop;
   int occ = 0;
   if (hipGetDevice(&t->device) != hipSuccess ||
@@ -541,7 +521,7 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
       hipMalloc((void **)&t->d_counters, kCounterRing * sizeof(unsigned int)) != hipSuccess ||
       hipMemcpy(t->d_slot_meta, meta.data(), meta.size() * sizeof(uint32_t),
                 hipMemcpyHostToDevice) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)var->solve, WAVE,
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, solve_kernel, is_block ? BLOCK_NT : WAVE,
                                                    t->smem_bytes) != hipSuccess) {
     if (t->d_slot_meta) (void)hipFree(t->d_slot_meta);
     if (t->d_counters) (void)hipFree(t->d_counters);
@@ -677,7 +657,16 @@ static int launch_kat(const gik_template *t, int mode, const double *d_Y, const 
   a.B = B;
   a.mode = mode;
   a.planar_proj_exact = t->p.planar_proj_exact;
-  hipLaunchKernelGGL(t->variant->kat, dim3(B), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
+  if (t->is_block) {
+    if (t->K == 3)
+      hipLaunchKernelGGL(kat_block_kernel<3>, dim3(B), dim3(BLOCK_NT), t->smem_bytes,
+                         (hipStream_t)stream, a, t->SL);
+    else
+      hipLaunchKernelGGL(kat_block_kernel<2>, dim3(B), dim3(BLOCK_NT), t->smem_bytes,
+                         (hipStream_t)stream, a, t->SL);
+  } else {
+    hipLaunchKernelGGL(t->variant->kat, dim3(B), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -741,8 +730,17 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   a.work_counter = t->d_counters + (mt->next_counter.fetch_add(1) % kCounterRing);
   HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned int), (hipStream_t)stream));
   const int grid = std::min(B, t->n_cu * t->waves_per_cu);
-  hipLaunchKernelGGL(t->variant->solve, dim3(grid), dim3(WAVE), t->smem_bytes,
-                     (hipStream_t)stream, a);
+  if (t->is_block) {
+    if (t->K == 3)
+      hipLaunchKernelGGL(rtr_block_kernel<3>, dim3(grid), dim3(BLOCK_NT), t->smem_bytes,
+                         (hipStream_t)stream, a, t->SL);
+    else
+      hipLaunchKernelGGL(rtr_block_kernel<2>, dim3(grid), dim3(BLOCK_NT), t->smem_bytes,
+                         (hipStream_t)stream, a, t->SL);
+  } else {
+    hipLaunchKernelGGL(t->variant->solve, dim3(grid), dim3(WAVE), t->smem_bytes,
+                       (hipStream_t)stream, a);
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -53,14 +53,14 @@ constexpr int WAVE = 64;
 #endif
 constexpr int TILE_ROWS = 33;  // 32 nodes max + one dump row for idle lanes
 
-// slot metadata word: [7:0] neighbour node j, [19:8] term index, [21:20] kind, [22] owner
+// slot metadata word: [7:0] neighbour node j, [23:8] term index, [25:24] kind, [26] owner
 __host__ __device__ inline uint32_t meta_pack(int j, int term, int kind, int owner) {
-  return (uint32_t)j | ((uint32_t)term << 8) | ((uint32_t)kind << 20) | ((uint32_t)owner << 22);
+  return (uint32_t)j | ((uint32_t)term << 8) | ((uint32_t)kind << 24) | ((uint32_t)owner << 26);
 }
 __host__ __device__ inline int meta_j(uint32_t m) { return (int)(m & 0xffu); }
-__device__ inline int meta_term(uint32_t m) { return (int)((m >> 8) & 0xfffu); }
-__device__ inline int meta_kind(uint32_t m) { return (int)((m >> 20) & 3u); }
-__device__ inline int meta_owner(uint32_t m) { return (int)((m >> 22) & 1u); }
+__device__ inline int meta_term(uint32_t m) { return (int)((m >> 8) & 0xffffu); }
+__device__ inline int meta_kind(uint32_t m) { return (int)((m >> 24) & 3u); }
+__device__ inline int meta_owner(uint32_t m) { return (int)((m >> 26) & 1u); }
 
 // ---- cross-lane primitives ---------------------------------------------------------------
 template <int CTRL>
@@ -243,6 +243,15 @@ struct WaveCtx {
 
   int lane, node, comp;
   bool active;
+
+  // reductions over the problem's unknowns (interface shared with the block context)
+  template <int NV>
+  __device__ inline void sum_n(double (&v)[NV]) {
+    wave_sum_n<NV>(v);
+  }
+  __device__ inline double sum1(double x) { return wave_sum(x); }
+  __device__ inline bool lead() const { return lane == 0; }
+
   double *sh_tile;         // K rotated tiles
   const double *sh_tgt;    // [T] per-problem residual targets
   const uint32_t *sh_meta; // [MAXDEG][64]

@@ -15,7 +15,8 @@ def env_world():
 
 def init_process_group(backend=None):
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # under torch.distributed.run
+    if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if backend is None:
@@ -36,7 +37,7 @@ def shard_range(total, rank, world):
 def gather_rows(local, total, dst=0):
     """Gather row-sharded tensors (shards as produced by shard_range) onto rank `dst`.
     Returns the [total, ...] tensor on dst, None elsewhere.  Single collective."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [shard_range(total, r, world) for r in range(world)]
@@ -56,12 +57,12 @@ def gather_rows(local, total, dst=0):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
 
 
 def max_over_ranks(value, device):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -69,7 +70,7 @@ def max_over_ranks(value, device):
 
 
 def sum_over_ranks(value, device):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -84,7 +84,8 @@ class Template:
             setattr(d, key, val)
         self.params = {f: getattr(d, f) for f in ("mingradnorm", "maxiter", "maxinner", "mininner",
                                                    "theta", "kappa", "rho_prime",
-                                                   "rho_regularization", "planar_proj_exact")}
+                                                   "rho_regularization", "planar_proj_exact",
+                                                   "force_block_path")}
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _ffi.check(self.lib.gik_template_create(C.byref(d), C.byref(h)))

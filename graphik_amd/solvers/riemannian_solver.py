@@ -39,7 +39,8 @@ class RiemannianSolver:
         self.tr_params = {"mingradnorm": params.get("mingradnorm", 0.5 * 1e-9),
                           "maxiter": int(params.get("maxiter", 3000)),
                           "theta": params.get("theta", 1.0), "kappa": params.get("kappa", 0.1)}
-        for k in ("maxinner", "mininner", "rho_prime", "rho_regularization", "planar_proj_exact"):
+        for k in ("maxinner", "mininner", "rho_prime", "rho_regularization", "planar_proj_exact",
+                  "force_block_path"):
             if k in params:
                 self.tr_params[k] = params[k]
         self.device = params.get("device", None)

@@ -65,6 +65,7 @@ typedef struct {
   double rho_prime;      /* 0.1                                                           */
   double rho_regularization; /* 1e3                                                       */
   int32_t planar_proj_exact; /* 0: reproduce fixed_rank_psd_sym.py:107-110 literally (k=2) */
+  int32_t force_block_path;  /* 1: use the workgroup-per-problem kernels even if N*k <= 64   */
 } gik_template_desc;
 
 typedef struct gik_template gik_template; /* opaque handle, immutable after creation */

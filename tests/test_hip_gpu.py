@@ -378,3 +378,83 @@ def test_device_pipeline_end_to_end(torch_cuda, name, B):
         assert ok.mean() > 0.9 and np.median(pos) < 1e-3
     else:
         assert ok.mean() > 0.97 and np.median(pos) < 1e-6
+
+
+# ---- workgroup-per-problem path (graphs with N*k > 64) -------------------------------------------
+@pytest.mark.parametrize("name", ["ur10_table", "lwa4d", "planar10_limits_halfpi"])
+def test_block_path_known_answers(torch_cuda, name):
+    """UR10 + table_environment(): 116 nodes, 5612 residual terms (BASELINE configs[2]) runs on
+    the workgroup-per-problem kernels; the small graphs are forced onto the same kernels so both
+    code paths are checked against the same golden vectors."""
+    from graphik_amd.engine import Template
+    d = load_golden(name)
+    use_lim = bool(int(d["use_limits"]))
+    T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=int(d["dim"]),
+                               use_limits=use_lim, params={"force_block_path": 1})
+    key = "lim" if use_lim else "nolim"
+    tg = T.targets_from_D(d["D_goal"][0])
+    Y, W = d["kat_Y"], d["kat_W"]
+    assert rel_err(T.cost(Y, tg).cpu().numpy(), d[f"kat_{key}_loop_cost"]) < 1e-12
+    assert rel_err(T.grad(Y, tg).cpu().numpy(), d[f"kat_{key}_loop_grad"]) < 1e-12
+    assert rel_err(T.hess(Y, W, tg).cpu().numpy(), d[f"kat_{key}_loop_hess"]) < 1e-12
+    assert rel_err(T.proj(Y, W).cpu().numpy(), d["kat_proj"]) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["lwa4d", "planar10_limits_halfpi"])
+def test_block_path_trajectories_match_wave_path(torch_cuda, name):
+    from graphik_amd.engine import Template
+    d = load_golden(name)
+    use_lim = bool(int(d["use_limits"]))
+    kw = dict(k=int(d["dim"]), use_limits=use_lim)
+    Tw = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], **kw)
+    Tb = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"force_block_path": 1}, **kw)
+    tg = Tw.targets_from_D(d["D_goal"])
+    rw = Tw.solve(d["Y_init"], tg, trace_cap=16)
+    rb = Tb.solve(d["Y_init"], tg, trace_cap=16)
+    m = 5 if int(d["dim"]) == 3 else 8
+    for key in ("numit", "stop", "accept", "Delta"):
+        assert np.array_equal(rw["trace"][key].cpu().numpy()[:, :m], rb["trace"][key].cpu().numpy()[:, :m])
+    assert np.allclose(rw["trace"]["f_before"].cpu().numpy()[:, :m],
+                       rb["trace"]["f_before"].cpu().numpy()[:, :m], rtol=1e-7)
+    fw, fb = rw["f"].cpu().numpy(), rb["f"].cpu().numpy()
+    assert np.array_equal(fw < 1e-9, fb < 1e-9)
+
+
+def test_ur10_table_solve(torch_cuda):
+    """BASELINE configs[2]: the captured goal, from the reference's own Y_init: trajectory prefix
+    against the oracle, convergence, and the EE error of the recovered configuration."""
+    from oracle import c_oracle as co
+    from graphik_amd.engine import Template
+    d = load_golden("ur10_table")
+    robot, graph = make_graph("ur10_table")
+    T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=3, use_limits=True)
+    reps = 8
+    r = T.solve(np.tile(d["Y_init"], (reps, 1, 1)), np.tile(T.targets_from_D(d["D_goal"]), (reps, 1)),
+                trace_cap=16)
+    x = r["x"].cpu().numpy()
+    assert np.array_equal(x[0], x[reps - 1])                      # deterministic across workgroups
+    o = co.rtr_solve(d["Y_init"][0], d["D_goal"][0], d["omega"], d["psi_L"], d["psi_U"], True,
+                     traj_cap=16)
+    tr = {k: v.cpu().numpy()[0] for k, v in r["trace"].items()}
+    m = 5
+    assert np.array_equal(tr["numit"][:m], o["traj"]["numit"][:m])
+    assert np.array_equal(tr["stop"][:m], o["traj"]["stop"][:m])
+    assert np.allclose(tr["f_before"][:m], o["traj"]["f_before"][:m], rtol=1e-6)
+    assert float(r["f"][0]) < 1e-12 and int(r["stop"][0]) == 0
+    its = int(r["iterations"][0])
+    assert 0.3 < its / int(d["iterations"][0]) < 3.0
+    q = graph.joint_variables(x[0], d["T_goal"][0])
+    T_sol = robot.pose(q, "p6")
+    assert np.linalg.norm(T_sol.trans - d["T_goal"][0][:3, 3]) < 5e-3
+
+
+def test_ur10_table_drop_in(torch_cuda):
+    """experiments/riemannian_example.py flow: load_ur10 + table obstacles + solve_with_riemannian."""
+    from graphik_amd.solvers.riemannian_solver import solve_with_riemannian
+    robot, graph = make_graph("ur10_table")
+    np.random.seed(0)
+    q_goal = robot.random_configuration()
+    T_goal = robot.pose(q_goal, f"p{robot.n}")
+    q_sol, Y = solve_with_riemannian(graph, T_goal, use_jit=False)
+    assert Y.shape == (116, 3)
+    assert np.linalg.norm(robot.pose(q_sol, "p6").trans - T_goal.trans) < 5e-3
