@@ -117,6 +117,7 @@ def main():
     Y0_h = res["Y0"].cpu().numpy()
 
     if rank != 0:
+        gd.shutdown()
         return
     st = allstats.cpu().numpy()
     pos, rot, its, inner, nacc, stop = st.T
@@ -181,7 +182,8 @@ def main():
             "sample": f"first {ns} goals of rank 0's batch, oracle/gik_oracle.c (-O3 AVX2+FMA), "
                       f"OpenMP over problems, {tc:.1f} s wall",
             "hv_total": int(o["inner_total"].sum())}
-    print(json.dumps(out))
+    gd.shutdown()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

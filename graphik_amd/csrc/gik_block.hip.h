@@ -312,14 +312,13 @@ struct BlockCtx {
 #pragma unroll
       for (int q = 0; q < NC; ++q) o[m] = fma(Pm[m * NC + q], v[q], o[m]);
       out = fma(-pk2[m], o[m], out);
-      dot = fma(-o[m], s_dpk[m], dot);
+      if constexpr (K == 2) dot = fma(-o[m], s_dpk[m], dot);
     }
+    if constexpr (K == 2) {
+      hd_pk[0] = fma(-o[0], G2[0], v[NC + 1]);
+    } else {
 #pragma unroll
-    for (int m = 0; m < NC; ++m) {
-      double t = (K == 3) ? v[m] : v[NC + 1];
-#pragma unroll
-      for (int q = 0; q < NC; ++q) t = fma(-o[q], G2[q * NC + m], t);
-      hd_pk[m] = t;
+      for (int m = 0; m < NC; ++m) hd_pk[m] = 0.0;  // see WaveCtx::hess_proj_dot
     }
     d_Hd = dot;
     return out;

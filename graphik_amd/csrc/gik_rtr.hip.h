@@ -65,6 +65,9 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
       const double target = norm_r0 * fmin(nr0_theta, p.kappa);  // rhs of :572
       const double target2 = target * target;
       double z_r = r_r, d_Pd = r_r;              // :464-466 (precon = identity)
+#if GIK_FASTDIV
+      double inv_z_r = frcp(z_r);
+#endif
       double delta = -r;                         // :469
       double e_Pd = 0.0, model_value = 0.0;      // :471,485
       int stop_tCG = TCG_MAX_INNER_ITER;         // :491
@@ -79,7 +82,11 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         double d_Hd;
         const double Hdelta = cx.hess_proj_dot(delta, s_pk, d_Hd, hd_pk);  // :497-500
         if (UNI(!(d_Hd == d_Hd))) { bad = true; break; }
-        const double alpha = fdiv(z_r, d_Hd);             // :503
+#if GIK_FASTDIV
+        const double alpha = z_r * frcp(d_Hd);            // :503
+#else
+        const double alpha = z_r / d_Hd;                  // :503
+#endif
         const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;  // :506
         if (UNI(d_Hd <= 0.0 || e_Pe_new >= Delta * Delta)) {   // :509
           const double tau =
@@ -117,12 +124,19 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         }
         const double zold_rold = z_r;                     // :587
         z_r = r_r;                                        // :589
-        const double beta = fdiv(z_r, zold_rold);         // :592
+#if GIK_FASTDIV
+        const double beta = z_r * inv_z_r;                // :592 (1/z_r_old, formed off the critical path)
+        inv_z_r = frcp(z_r);
+#else
+        const double beta = z_r / zold_rold;              // :592
+#endif
         delta = -r + beta * delta;                        // :593
+        if constexpr (K == 2) {                           // the same two updates seen through pk2
 #pragma unroll
-        for (int m = 0; m < Ctx::NC; ++m) {               // the same two updates seen through pk2
-          rho_pk[m] = fma(alpha, hd_pk[m], rho_pk[m]);
-          s_pk[m] = fma(beta, s_pk[m], -rho_pk[m]);
+          for (int m = 0; m < Ctx::NC; ++m) {
+            rho_pk[m] = fma(alpha, hd_pk[m], rho_pk[m]);
+            s_pk[m] = fma(beta, s_pk[m], -rho_pk[m]);
+          }
         }
         e_Pd = beta * (e_Pd + alpha * d_Pd);              // :596
         d_Pd = z_r + beta * beta * d_Pd;                  // :597

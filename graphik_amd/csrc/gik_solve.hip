@@ -56,7 +56,7 @@ __device__ inline void stage_lds(double *tiles, uint32_t *meta, const uint32_t *
 // hardware hands workgroups to XCDs round-robin, so a static block->problem map leaves whole
 // XCDs idle behind a few stragglers; the queue keeps every SIMD busy until the end.
 template <int K, int MAXDEG>
-__global__ void __launch_bounds__(WAVE) rtr_wave_kernel(SolveArgs a) {
+__global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
   using Ctx = WaveCtx<K, MAXDEG>;
   extern __shared__ double smem[];
   const int lane = threadIdx.x;

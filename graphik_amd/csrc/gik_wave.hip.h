@@ -43,7 +43,7 @@ constexpr int WAVE = 64;
 #define GIK_TREDUCE 1   // 1: MFMA (v_mfma_f64_4x4x4) wave reductions, 0: DPP butterfly
 #endif
 #ifndef GIK_FASTDIV
-#define GIK_FASTDIV 0   // 1: Newton reciprocal division for alpha/beta
+#define GIK_FASTDIV 1   // 1: reciprocal-multiply for alpha/beta (<= 2 ulp), 0: IEEE division
 #endif
 #ifndef GIK_TREESUM
 #define GIK_TREESUM 1   // 1: pairwise tree for the slot sum of the Hessian-vector product
@@ -195,18 +195,16 @@ __device__ inline double wave_sum(double x) {
   return v[0];
 }
 
-// a / b with one Newton-refined reciprocal and a residual correction: <= 1 ulp from the IEEE
-// quotient at a third of the instruction count of the correctly rounded sequence
-__device__ inline double fdiv(double a, double b) {
-#if GIK_FASTDIV
-  double r = __builtin_amdgcn_rcp(b);
-  r = fma(fma(-b, r, 1.0), r, r);
-  r = fma(fma(-b, r, 1.0), r, r);
-  const double q = a * r;
-  return fma(fma(-b, q, a), r, q);
-#else
-  return a / b;
-#endif
+// 1 / b to about one ulp with a short dependency chain: v_rcp_f64 seed (error e ~ 2^-26),
+// r1 = r0 (1 + e) and e^2 evaluated side by side, r2 = r1 (1 + e^2).  A lone wavefront waits ~28
+// cycles on every dependent fp64 op and IEEE division is a 10-deep chain, so the two divisions of
+// a tCG iteration (alpha = z_r / d_Hd, beta = z_r' / z_r) were ~20 % of its critical path.
+// GIK_FASTDIV=0 restores correctly rounded division.
+__device__ inline double frcp(double b) {
+  const double r0 = __builtin_amdgcn_rcp(b);
+  const double e = fma(-b, r0, 1.0);
+  const double r1 = fma(e, r0, r0);
+  return fma(r1, e * e, r1);
 }
 
 // ---- solver parameters handed to the kernels ----------------------------------------------
@@ -587,14 +585,18 @@ struct WaveCtx {
 #pragma unroll
       for (int q = 0; q < NC; ++q) o[m] = fma(Pm[m * NC + q], v[q], o[m]);
       out = fma(-pk2[m], o[m], out);
-      dot = fma(-o[m], s_dpk[m], dot);
+      if constexpr (K == 2) dot = fma(-o[m], s_dpk[m], dot);
     }
+    if constexpr (K == 2) {
+      // non-orthogonal (literal k=2) projector: <delta, pk2> is not small, carry it exactly
+      hd_pk[0] = fma(-o[0], G2[0], v[NC + 1]);
+    } else {
+      // k=3: proj is the orthogonal projector onto the horizontal space and delta is horizontal
+      // up to round-off, so <delta, pk_m> = O(eps |delta||pk|) and the correction
+      // sum_m o_m <delta, pk_m> is below the rounding error of <delta, H> itself: it is dropped
+      // (<Hdelta, pk_m> = (I - M M^-1) v is pure round-off as well).
 #pragma unroll
-    for (int m = 0; m < NC; ++m) {
-      double t = (K == 3) ? v[m] : v[NC + 1];
-#pragma unroll
-      for (int q = 0; q < NC; ++q) t = fma(-o[q], G2[q * NC + m], t);
-      hd_pk[m] = t;
+      for (int m = 0; m < NC; ++m) hd_pk[m] = 0.0;
     }
     d_Hd = dot;
     return out;
