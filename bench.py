@@ -49,7 +49,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="goals per GPU")
-    ap.add_argument("--robot", default="lwa4d", choices=["lwa4d", "ur10", "kuka"])
+    ap.add_argument("--robot", default="lwa4d",
+                    choices=["lwa4d", "ur10", "kuka", "planar10", "planar10_halfpi"],
+                    help="lwa4d = BASELINE configs[1] (the bench line); the others are the parity "
+                         "configs, runnable here for reference numbers")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="problems for the CPU baseline (0=auto)")
@@ -63,7 +66,19 @@ def main():
 
     from graphik_amd.utils.roboturdf import load_schunk_lwa4d, load_ur10, load_kuka
     from graphik_amd.solvers.riemannian_solver import BatchProblem
-    robot, graph = {"lwa4d": load_schunk_lwa4d, "ur10": load_ur10, "kuka": load_kuka}[args.robot]()
+    if args.robot.startswith("planar10"):
+        from graphik_amd.robots import RobotPlanar
+        from graphik_amd.graphs import ProblemGraphPlanar
+        from graphik_amd.utils import list_to_variable_dict
+        nl = 10
+        lim = np.array(9 * [np.pi / 2] + [np.pi]) if args.robot.endswith("halfpi") else np.pi * np.ones(nl)
+        robot = RobotPlanar({"link_lengths": list_to_variable_dict(np.ones(nl)),
+                             "theta": list_to_variable_dict(np.zeros(nl)),
+                             "joint_limits_upper": list_to_variable_dict(lim),
+                             "joint_limits_lower": list_to_variable_dict(-lim), "num_joints": nl})
+        graph = ProblemGraphPlanar(robot)
+    else:
+        robot, graph = {"lwa4d": load_schunk_lwa4d, "ur10": load_ur10, "kuka": load_kuka}[args.robot]()
     prob = BatchProblem(graph, use_limits=True, device=dev)
     B = args.batch
     N, k, T, n = graph.number_of_nodes(), graph.dim, prob.template.T, robot.n
@@ -150,7 +165,7 @@ def main():
         "frac_maxiter": float(np.mean(stop == 1)),
         "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": None,
-                     "kernel": "rtr_wave_kernel<3,10>", "kernel_ms": kernel_ms,
+                     "kernel": f"rtr_wave_kernel<{k},{prob.template.maxdeg}>", "kernel_ms": kernel_ms,
                      "kernel_share_of_step": kernel_ms / (dt_local / args.steps * 1e3),
                      "flops_per_launch": flops,
                      "note": "fp64; the solve is LDS/register resident and bound by dependent "
