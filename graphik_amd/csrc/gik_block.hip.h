@@ -37,7 +37,7 @@ struct BlockCtx {
   const uint32_t *sh_slots;  // [SL][512]
   double *sh_red;            // [2][8][BLOCK_WAVES]
   int red_buf;
-  double pk[NC], pk2[NC], Pm[NC * NC], G2[NC * NC];
+  double pk[NC], pk2[NC], Pm[NC * NC], G2[NC * NC], Q[NC];
 
   __host__ __device__ static constexpr size_t lds_bytes(int T, int SL) {
     return sizeof(double) * ((size_t)3 * BLOCK_MAXN * RS + (size_t)((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES) +
@@ -114,6 +114,7 @@ struct BlockCtx {
     double own[K];
     row(sh_P, node < N ? node : 0, own);
     double f = 0.0;
+#pragma unroll 4
     for (int s = 0; s < SL; ++s) {
       const uint32_t m = sh_slots[s * BLOCK_NT + tid];
       double r[K];
@@ -142,6 +143,7 @@ struct BlockCtx {
     double acc[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = 0.0;
+#pragma unroll 4
     for (int s = 0; s < SL; ++s) {
       const uint32_t m = sh_slots[s * BLOCK_NT + tid];
       double r[K], y[K];
@@ -177,6 +179,7 @@ struct BlockCtx {
     double acc[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = 0.0;
+#pragma unroll 4
     for (int s = 0; s < SL; ++s) {
       const uint32_t m = sh_slots[s * BLOCK_NT + tid];
       const int j = meta_j(m);
@@ -230,6 +233,7 @@ struct BlockCtx {
       pk[0] = pk2[0] = am * (e1 * y0 - e0 * y1);
       pk[1] = pk2[1] = am * (e2 * y0 - e0 * y2);
       pk[2] = pk2[2] = am * (e2 * y1 - e1 * y2);
+      vertical_basis(a, b, c, d, e, f, pk, Q);
     } else {
       const double y0 = own[0], y1 = own[1];
       double x[3] = {lm * y0 * y0, lm * y0 * y1, lm * y1 * y1};
@@ -274,11 +278,18 @@ struct BlockCtx {
       pk2[0] = am * (e0 * (y0 * u0 + y1 * u2) + e1 * (y0 * u1 + y1 * u3));
       Pm[0] = 1.0;
       G2[0] = sum1(pk2[0] * pk2[0]);
+      Q[0] = 0.0;
     }
   }
 
   __device__ inline double proj(double Z) {
     double v[NC];
+    if constexpr (K == 3) {
+#pragma unroll
+      for (int m = 0; m < NC; ++m) v[m] = Q[m] * Z;
+      sum_n<NC>(v);
+      return fma(-Q[2], v[2], fma(-Q[1], v[1], fma(-Q[0], v[0], Z)));
+    }
 #pragma unroll
     for (int m = 0; m < NC; ++m) v[m] = pk[m] * Z;
     sum_n<NC>(v);
@@ -296,8 +307,11 @@ struct BlockCtx {
   // same contract as WaveCtx::hess_proj_dot
   __device__ inline double hess_proj_dot(double delta, const double (&s_dpk)[NC], double &d_Hd,
                                          double (&hd_pk)[NC]) {
+    return proj_dot(ehess(delta), delta, s_dpk, d_Hd, hd_pk);
+  }
+  __device__ inline double proj_dot(double H, double delta, const double (&s_dpk)[NC], double &d_Hd,
+                                    double (&hd_pk)[NC]) {
     constexpr int NV = (K == 3) ? NC + 1 : NC + 2;
-    const double H = ehess(delta);
     double v[NV];
 #pragma unroll
     for (int m = 0; m < NC; ++m) v[m] = pk[m] * H;

@@ -52,95 +52,214 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
     double rho0[Ctx::NC];
     double norm_grad = grad_norm_and_rho(cx, g, rho0);
     int kiter = 0, inner_total = 0, n_accept = 0, stop = 1;
+    const bool prof = (dbg & 8) && b == 0 && dbg_buf;   // cycle counters (developer aid)
+    long long prof_tcg = 0;
+    const long long prof_t0 = prof ? (long long)__builtin_readcyclecounter() : 0;
     bool bad = UNI(!(fx == fx) || !(norm_grad == norm_grad));
     if (dbg & 2) bad = true;
 
     while (!bad) {
       // -------------- _truncated_conjugate_gradient (trust_region.py:436-599) -------------
-      double eta = 0.0, Heta = 0.0, r = g;       // :444-448
-      double e_Pe = 0.0;
-      double r_r = cx.sum1(r * r);              // :455
-      const double norm_r0 = sqrt(r_r);
-      const double nr0_theta = (p.theta == 1.0) ? norm_r0 : pow(norm_r0, p.theta);
-      const double target = norm_r0 * fmin(nr0_theta, p.kappa);  // rhs of :572
-      const double target2 = target * target;
-      double z_r = r_r, d_Pd = r_r;              // :464-466 (precon = identity)
-#if GIK_FASTDIV
-      double inv_z_r = frcp(z_r);
-#endif
-      double delta = -r;                         // :469
-      double e_Pd = 0.0, model_value = 0.0;      // :471,485
+      double eta = 0.0, Heta = 0.0;              // :444-445
       int stop_tCG = TCG_MAX_INNER_ITER;         // :491
-      double rho_pk[Ctx::NC], s_pk[Ctx::NC], hd_pk[Ctx::NC];  // <r,pk2>, <delta,pk2>, <Hdelta,pk2>
-#pragma unroll
-      for (int m = 0; m < Ctx::NC; ++m) {
-        rho_pk[m] = rho0[m];
-        s_pk[m] = -rho0[m];
-      }
       int j = 0;
-      for (j = 0; j < p.maxinner; ++j) {         // :495
-        double d_Hd;
-        const double Hdelta = cx.hess_proj_dot(delta, s_pk, d_Hd, hd_pk);  // :497-500
-        if (UNI(!(d_Hd == d_Hd))) { bad = true; break; }
-#if GIK_FASTDIV
-        const double alpha = z_r * frcp(d_Hd);            // :503
-#else
-        const double alpha = z_r / d_Hd;                  // :503
-#endif
-        const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;  // :506
-        if (UNI(d_Hd <= 0.0 || e_Pe_new >= Delta * Delta)) {   // :509
-          const double tau =
-              (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta * Delta - e_Pe))) / d_Pd;  // :514
-          eta = eta + tau * delta;                        // :516
-          Heta = Heta + tau * Hdelta;                     // :521
-          stop_tCG = (d_Hd <= 0.0) ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;  // :531-534
-          break;
+      const long long prof_t1 = prof ? (long long)__builtin_readcyclecounter() : 0;
+      if constexpr (K == 3) {
+        // One reduction per inner iteration.  All tangent vectors of the recurrences are
+        // horizontal (the Euclidean gradient of a rotation-invariant cost is, and every Hdelta is
+        // projected), the raw Hessian is symmetric and the projector P = I - Q Q^T is orthogonal,
+        // so with H = ehess(delta), u = Q^T H, Hdelta = H - Q u:
+        //     <delta, Hdelta> = <delta, H>     <r, Hdelta> = <r, H>     |Hdelta|^2 = |H|^2 - u.u
+        // Everything the textbook loop reduces AFTER its vector updates is either predicted from
+        // these, or reduced one iteration late next to them:
+        //   * <r', r'> = <r, r> + 2 alpha <r, Hdelta> + alpha^2 |Hdelta|^2 gives beta (:592) and
+        //     the residual test (:572) at once; the exact <r', r'> arrives with the next
+        //     iteration's reduction and is what alpha (:503) uses, as in the reference.  The
+        //     prediction loses digits when the residual drops sharply; below 1e-3 <r, r> it is
+        //     re-reduced directly (rare).
+        //   * the model value <eta, g> + 1/2 <eta, Heta> (:551) of the CURRENT eta rides along as
+        //     one more summand, so the "model increased" test (:552) of step j-1 is taken at the top
+        //     of step j -- before anything of step j is used, which is the reference's order --
+        //     and rolls eta back one step.  It is a fresh inner product, not a recurrence: the
+        //     test exists to catch round-off stagnation and must see the same noise as the
+        //     reference's.  Where the reference would test the model before leaving (residual
+        //     target reached, inner iterations exhausted) the pending test is reduced on the spot.
+        // One branch covers all exits.  Reported inner iteration counts are the reference's (a
+        // rolled-back step has cost one extra Hessian product that is not counted).
+        double r = g;                              // :448
+        const double r0_r0 = norm_grad * norm_grad;   // :455 (r = grad: same sum as ||grad||^2)
+        const double nr0_theta = (p.theta == 1.0) ? norm_grad : pow(norm_grad, p.theta);
+        const double target = norm_grad * fmin(nr0_theta, p.kappa);  // rhs of :572
+        const double target2 = target * target;
+        const double Delta2 = Delta * Delta;
+        double delta = -r;                         // :469
+        double e_Pe = 0.0, e_Pd = 0.0, d_Pd = r0_r0;  // :464-471 (precon = identity)
+        double model_prev = __builtin_inf();       // model value before the last step (:485: 0)
+        double eta_prev = 0.0, Heta_prev = 0.0;
+        for (j = 0; j < p.maxinner; ++j) {         // :495
+          const double H = cx.ehess(delta);        // :497
+          double v[8] = {cx.Q[0] * H, cx.Q[1] * H, cx.Q[2] * H,      delta * H,
+                         r * H,       H * H,       eta * fma(0.5, Heta, g), r * r};
+          cx.template sum_n<8>(v);
+          const double Hdelta = fma(-cx.Q[2], v[2], fma(-cx.Q[1], v[1], fma(-cx.Q[0], v[0], H)));
+          const double d_Hd = v[3];                // :500
+          const double Hd_Hd = fma(-v[2], v[2], fma(-v[1], v[1], fma(-v[0], v[0], v[5])));
+          const double model_value = v[6];         // :551 evaluated at the current eta
+          const double r_r = v[7];                 // :564 exact
+          const double alpha = r_r * frcp1(d_Hd);  // :503
+          const double a2 = alpha + alpha;
+          const double e_Pe_new = fma(alpha, fma(alpha, d_Pd, 2.0 * e_Pd), e_Pe);      // :506
+          double new_r_r = fma(alpha, fma(alpha, Hd_Hd, v[4] + v[4]), r_r);            // :564 predicted
+          const double new_eta = fma(alpha, delta, eta);      // :538
+          const double new_Heta = fma(alpha, Hdelta, Heta);   // :542
+          const double new_r = fma(alpha, Hdelta, r);         // :561
+          const double beta_p = new_r_r * frcp1(r_r);         // :592
+          const bool plain = model_value < model_prev && d_Hd > 0.0 && e_Pe_new < Delta2 &&
+                             beta_p >= 1e-3 && !(j >= p.mininner && new_r_r <= target2);
+          double beta = beta_p;
+          (void)a2;
+          if (UNI(!plain)) {   // any exit, a NaN, or the accuracy guard
+            if (!(d_Hd == d_Hd) || !(new_r_r == new_r_r) || !(model_value == model_value)) {
+              bad = true;
+              break;
+            }
+            if (model_value >= model_prev) {                    // :552 of step j-1
+              eta = eta_prev;
+              Heta = Heta_prev;
+              stop_tCG = TCG_MODEL_INCREASED;
+              j = j - 1;
+              break;
+            }
+            if (d_Hd <= 0.0 || e_Pe_new >= Delta2) {           // :509
+              const double tau = (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta2 - e_Pe))) / d_Pd;  // :514
+              eta = eta + tau * delta;                          // :516
+              Heta = Heta + tau * Hdelta;                       // :521
+              stop_tCG = (d_Hd <= 0.0) ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;  // :531-534
+              break;
+            }
+            if (beta_p < 1e-3) {
+              new_r_r = cx.sum1(new_r * new_r);
+              beta = new_r_r / r_r;
+            }
+            if (j >= p.mininner && new_r_r <= target2) {        // :572
+              // the reference tests the model of this step first (:552)
+              const double model_new = cx.sum1(new_eta * fma(0.5, new_Heta, g));
+              if (model_new >= model_value) {
+                stop_tCG = TCG_MODEL_INCREASED;
+              } else {
+                eta = new_eta;
+                Heta = new_Heta;
+                stop_tCG = (p.kappa < nr0_theta) ? TCG_REACHED_TARGET_LINEAR
+                                                 : TCG_REACHED_TARGET_SUPERLINEAR;
+              }
+              break;
+            }
+          }
+          e_Pe = e_Pe_new;                                  // :537
+          eta_prev = eta;
+          Heta_prev = Heta;
+          model_prev = model_value;
+          eta = new_eta;                                    // :556-558
+          Heta = new_Heta;
+          r = new_r;                                        // :561
+          delta = fma(beta, delta, -r);                     // :593
+          e_Pd = beta * fma(alpha, d_Pd, e_Pd);             // :596
+          d_Pd = fma(beta * beta, d_Pd, new_r_r);           // :597
         }
-        if ((dbg & 4) && b == 0 && lead && dbg_buf && kiter < 64 && j < 128) {
-          double *q = dbg_buf + ((size_t)kiter * 128 + j) * 4;
-          q[0] = r_r; q[1] = d_Hd; q[2] = alpha; q[3] = model_value;
-        }
-        e_Pe = e_Pe_new;                                  // :537
-        const double new_eta = eta + alpha * delta;       // :538
-        const double new_Heta = Heta + alpha * Hdelta;    // :542
-        const double new_r = r + alpha * Hdelta;          // :561 (speculative; same value)
-        double m[3] = {new_eta * g, new_eta * new_Heta, new_r * new_r};
-        cx.template sum_n<3>(m);
-        const double new_model_value = m[0] + 0.5 * m[1]; // :551
-        if (UNI(new_model_value >= model_value)) {        // :552
-          stop_tCG = TCG_MODEL_INCREASED;
-          break;
-        }
-        eta = new_eta;                                    // :556-558
-        Heta = new_Heta;
-        model_value = new_model_value;
-        r = new_r;                                        // :561
-        r_r = m[2];                                       // :564
-        // :572  norm_r <= norm_r0*min(norm_r0^theta, kappa), compared on the squares
-        if (UNI(j >= p.mininner && r_r <= target2)) {
-          stop_tCG = (p.kappa < nr0_theta) ? TCG_REACHED_TARGET_LINEAR
-                                           : TCG_REACHED_TARGET_SUPERLINEAR;
-          break;
-        }
-        const double zold_rold = z_r;                     // :587
-        z_r = r_r;                                        // :589
-#if GIK_FASTDIV
-        const double beta = z_r * inv_z_r;                // :592 (1/z_r_old, formed off the critical path)
-        inv_z_r = frcp(z_r);
-#else
-        const double beta = z_r / zold_rold;              // :592
-#endif
-        delta = -r + beta * delta;                        // :593
-        if constexpr (K == 2) {                           // the same two updates seen through pk2
-#pragma unroll
-          for (int m = 0; m < Ctx::NC; ++m) {
-            rho_pk[m] = fma(alpha, hd_pk[m], rho_pk[m]);
-            s_pk[m] = fma(beta, s_pk[m], -rho_pk[m]);
+        if (!bad && j >= p.maxinner) {
+          // inner iterations exhausted with the model test of the last step still pending
+          const double model_last = cx.sum1(eta * fma(0.5, Heta, g));
+          if (model_last >= model_prev) {
+            eta = eta_prev;
+            Heta = Heta_prev;
+            stop_tCG = TCG_MODEL_INCREASED;
           }
         }
-        e_Pd = beta * (e_Pd + alpha * d_Pd);              // :596
-        d_Pd = z_r + beta * beta * d_Pd;                  // :597
+      } else {
+        double r = g;                              // :448
+        double e_Pe = 0.0;
+        double r_r = cx.sum1(r * r);              // :455
+        const double norm_r0 = sqrt(r_r);
+        const double nr0_theta = (p.theta == 1.0) ? norm_r0 : pow(norm_r0, p.theta);
+        const double target = norm_r0 * fmin(nr0_theta, p.kappa);  // rhs of :572
+        const double target2 = target * target;
+        double z_r = r_r, d_Pd = r_r;              // :464-466 (precon = identity)
+#if GIK_FASTDIV
+        double inv_z_r = frcp(z_r);
+#endif
+        double delta = -r;                         // :469
+        double e_Pd = 0.0, model_value = 0.0;      // :471,485
+        double rho_pk[Ctx::NC], s_pk[Ctx::NC], hd_pk[Ctx::NC];  // <r,pk2>, <delta,pk2>, <Hdelta,pk2>
+#pragma unroll
+        for (int m = 0; m < Ctx::NC; ++m) {
+          rho_pk[m] = rho0[m];
+          s_pk[m] = -rho0[m];
+        }
+        for (j = 0; j < p.maxinner; ++j) {         // :495
+          double d_Hd;
+          const double Hdelta = cx.hess_proj_dot(delta, s_pk, d_Hd, hd_pk);  // :497-500
+          if (UNI(!(d_Hd == d_Hd))) { bad = true; break; }
+#if GIK_FASTDIV
+          const double alpha = z_r * frcp(d_Hd);            // :503
+#else
+          const double alpha = z_r / d_Hd;                  // :503
+#endif
+          const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;  // :506
+          if (UNI(d_Hd <= 0.0 || e_Pe_new >= Delta * Delta)) {   // :509
+            const double tau =
+                (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta * Delta - e_Pe))) / d_Pd;  // :514
+            eta = eta + tau * delta;                        // :516
+            Heta = Heta + tau * Hdelta;                     // :521
+            stop_tCG = (d_Hd <= 0.0) ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;  // :531-534
+            break;
+          }
+          if ((dbg & 4) && b == 0 && lead && dbg_buf && kiter < 64 && j < 128) {
+            double *q = dbg_buf + ((size_t)kiter * 128 + j) * 4;
+            q[0] = r_r; q[1] = d_Hd; q[2] = alpha; q[3] = model_value;
+          }
+          e_Pe = e_Pe_new;                                  // :537
+          const double new_eta = eta + alpha * delta;       // :538
+          const double new_Heta = Heta + alpha * Hdelta;    // :542
+          const double new_r = r + alpha * Hdelta;          // :561 (speculative; same value)
+          double m[3] = {new_eta * g, new_eta * new_Heta, new_r * new_r};
+          cx.template sum_n<3>(m);
+          const double new_model_value = m[0] + 0.5 * m[1]; // :551
+          if (UNI(new_model_value >= model_value)) {        // :552
+            stop_tCG = TCG_MODEL_INCREASED;
+            break;
+          }
+          eta = new_eta;                                    // :556-558
+          Heta = new_Heta;
+          model_value = new_model_value;
+          r = new_r;                                        // :561
+          r_r = m[2];                                       // :564
+          // :572  norm_r <= norm_r0*min(norm_r0^theta, kappa), compared on the squares
+          if (UNI(j >= p.mininner && r_r <= target2)) {
+            stop_tCG = (p.kappa < nr0_theta) ? TCG_REACHED_TARGET_LINEAR
+                                             : TCG_REACHED_TARGET_SUPERLINEAR;
+            break;
+          }
+          const double zold_rold = z_r;                     // :587
+          z_r = r_r;                                        // :589
+#if GIK_FASTDIV
+          const double beta = z_r * inv_z_r;                // :592 (1/z_r_old, formed off the critical path)
+          inv_z_r = frcp(z_r);
+#else
+          const double beta = z_r / zold_rold;              // :592
+#endif
+          delta = -r + beta * delta;                        // :593
+          if constexpr (K == 2) {                           // the same two updates seen through pk2
+#pragma unroll
+            for (int m = 0; m < Ctx::NC; ++m) {
+              rho_pk[m] = fma(alpha, hd_pk[m], rho_pk[m]);
+              s_pk[m] = fma(beta, s_pk[m], -rho_pk[m]);
+            }
+          }
+          e_Pd = beta * (e_Pd + alpha * d_Pd);              // :596
+          d_Pd = z_r + beta * beta * d_Pd;                  // :597
+        }
       }
+      if (prof) prof_tcg += (long long)__builtin_readcyclecounter() - prof_t1;
       if (bad) break;
       if (j >= p.maxinner) j = p.maxinner - 1;  // Python leaves j at the last index
       inner_total += j + 1;
@@ -194,6 +313,11 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
       if (UNI(!(norm_grad == norm_grad) || !(fx == fx))) { bad = true; break; }
     }
     if (bad) stop = 2;
+    if (prof && lead) {
+      dbg_buf[0] = (double)prof_tcg;
+      dbg_buf[1] = (double)inner_total;
+      dbg_buf[2] = (double)((long long)__builtin_readcyclecounter() - prof_t0);
+    }
 
     out.f = fx;
     out.gradnorm = norm_grad;

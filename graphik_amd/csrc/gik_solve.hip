@@ -36,7 +36,8 @@ struct SolveArgs {
   int has_trace;
   int N, T, B;
   int dbg;  // debug flags (env GIK_DBG): 1 = one block per problem, 2 = skip the TR loop,
-            // 4 = dump (r_r, d_Hd, alpha, model) of every inner iteration of problem 0 to dbg_buf
+            // 4 = dump (r_r, d_Hd, alpha, model) of every inner iteration of problem 0 to dbg_buf,
+            // 8 = cycle counters of problem 0: dbg_buf = {cycles in tCG loops, tCG iterations, all cycles}
   double *dbg_buf;
   Params p;
 };
@@ -255,26 +256,47 @@ __global__ void __launch_bounds__(WAVE) parts_kernel(const uint32_t *slot_meta, 
   cx.proj_setup(0);
   double acc = g, sc = 1.0;
   const long long t0 = __builtin_readcyclecounter();
-  for (int it = 0; it < iters; ++it) {
-    if (mode == 0) {            // ehess only
+  if (mode == 0) {
+    for (int it = 0; it < iters; ++it) {            // ehess only
       acc = cx.ehess(acc) * 1e-3 + g;
-    } else if (mode == 1) {     // 3-value reduction
+    }
+  }
+  else if (mode == 1) {
+    for (int it = 0; it < iters; ++it) {     // 3-value reduction
       double v[3] = {acc, acc * 0.5, acc * 0.25};
       wave_sum_n<3>(v);
       acc = g + 1e-3 * (v[0] + v[1] + v[2]);
-    } else if (mode == 2) {     // 1-value reduction
+    }
+  }
+  else if (mode == 2) {
+    for (int it = 0; it < iters; ++it) {     // 1-value reduction
       acc = g + 1e-3 * wave_sum(acc);
-    } else if (mode == 3) {     // fp64 division chain
+    }
+  }
+  else if (mode == 3) {
+    for (int it = 0; it < iters; ++it) {     // fp64 division chain
       sc = 1.0 / (sc + 1.5);
       acc = acc + sc;
-    } else if (mode == 4) {     // proj(ehess)
+    }
+  }
+  else if (mode == 4) {
+    for (int it = 0; it < iters; ++it) {     // proj(ehess)
       acc = cx.proj(cx.ehess(acc)) * 1e-3 + g;
-    } else if (mode == 5) {     // dependent fma chain (8 per iteration)
+    }
+  }
+  else if (mode == 5) {
+    for (int it = 0; it < iters; ++it) {     // dependent fma chain (8 per iteration)
       for (int q = 0; q < 8; ++q) acc = fma(acc, 0.999, g);
-    } else if (mode == 6) {     // sqrt chain
+    }
+  }
+  else if (mode == 6) {
+    for (int it = 0; it < iters; ++it) {     // sqrt chain
       sc = sqrt(sc + 1.5);
       acc = acc + sc;
-    } else if (mode == 7) {     // 8 independent fma chains x 8 (64 fma / iteration)
+    }
+  }
+  else if (mode == 7) {
+    for (int it = 0; it < iters; ++it) {     // 8 independent fma chains x 8 (64 fma / iteration)
       double c0 = acc, c1 = acc + 1, c2 = acc + 2, c3 = acc + 3, c4 = acc + 4, c5 = acc + 5,
              c6 = acc + 6, c7 = acc + 7;
       for (int q = 0; q < 8; ++q) {
@@ -283,17 +305,84 @@ __global__ void __launch_bounds__(WAVE) parts_kernel(const uint32_t *slot_meta, 
         c6 = fma(c6, 0.999, g); c7 = fma(c7, 0.999, g);
       }
       acc = ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7));
-    } else if (mode == 8) {     // LDS write + dependent read round trip
+    }
+  }
+  else if (mode == 8) {
+    for (int it = 0; it < iters; ++it) {     // LDS write + dependent read round trip
       cx.put(acc);
       acc = cx.read_row(cx.own_off).v[1] + g;
-    } else if (mode == 9) {     // one DPP move + add (dependent)
+    }
+  }
+  else if (mode == 9) {
+    for (int it = 0; it < iters; ++it) {     // one DPP move + add (dependent)
       acc = acc + dpp_f64<0xB1>(acc) * 1e-3;
-    } else if (mode == 10) {    // readlane + add (dependent)
+    }
+  }
+  else if (mode == 10) {
+    for (int it = 0; it < iters; ++it) {    // readlane + add (dependent)
       acc = g + readlane_f64(acc, 17) * 1e-3;
-    } else if (mode == 11) {    // 8 dependent f32 fma
+    }
+  }
+  else if (mode == 11) {
+    for (int it = 0; it < iters; ++it) {    // 8 dependent f32 fma
       float fa = (float)acc;
       for (int q = 0; q < 8; ++q) fa = fmaf(fa, 0.999f, 0.5f);
       acc = fa;
+    }
+  }
+  else if (mode == 12 || mode == 13 || mode == 14) {
+    for (int it = 0; it < iters; ++it) {  // 64 independent add / mul / fma(vvv)
+      double c0 = acc, c1 = acc + 1, c2 = acc + 2, c3 = acc + 3, c4 = acc + 4, c5 = acc + 5,
+             c6 = acc + 6, c7 = acc + 7;
+      const double h = g * 0.5 + 1.0;
+#define OP8(EXPR)                                                                    \
+  for (int q = 0; q < 8; ++q) {                                                      \
+    { double &c = c0; c = EXPR; } { double &c = c1; c = EXPR; } { double &c = c2; c = EXPR; } \
+    { double &c = c3; c = EXPR; } { double &c = c4; c = EXPR; } { double &c = c5; c = EXPR; } \
+    { double &c = c6; c = EXPR; } { double &c = c7; c = EXPR; }                        \
+  }
+      if (mode == 12) { OP8(c + g) } else if (mode == 13) { OP8(c * h) } else { OP8(fma(c, h, g)) }
+      acc = ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7));
+    }
+  }
+  else if (mode == 15) {
+    for (int it = 0; it < iters; ++it) {    // 64 independent 32-bit ops (v_add_u32 / xor mix)
+      int c[8];
+      for (int q = 0; q < 8; ++q) c[q] = __double2loint(acc) + q;
+      for (int q = 0; q < 8; ++q)
+        for (int w = 0; w < 8; ++w) c[w] = (c[w] ^ (c[w] >> 3)) + lane;   // 3 ops each
+      int z = 0;
+      for (int q = 0; q < 8; ++q) z ^= c[q];
+      acc = g + 1e-9 * z;
+    }
+  }
+  else if (mode == 16) {
+    for (int it = 0; it < iters; ++it) {    // 32 independent DPP f64 moves (64 v_mov_dpp) + adds
+      double c[8];
+      for (int q = 0; q < 8; ++q) c[q] = acc + q;
+      for (int q = 0; q < 4; ++q)
+        for (int w = 0; w < 8; ++w) c[w] = dpp_f64<0xB1>(c[w]);
+      acc = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+    }
+  }
+  else if (mode == 17) {
+    for (int it = 0; it < iters; ++it) {    // 32 selects on f64 (64 v_cndmask)
+      double c[8];
+      for (int q = 0; q < 8; ++q) c[q] = acc + q;
+      for (int q = 0; q < 4; ++q)
+        for (int w = 0; w < 8; ++w) c[w] = ((lane >> q) & 1) ? c[w] : c[(w + 1) & 7];
+      acc = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+    }
+  }
+  else if (mode == 18) {
+    for (int it = 0; it < iters; ++it) {    // 11 x (ds_read_b128 + ds_read_b64) of the gather, no math
+      cx.put(acc);
+      double z = 0.0;
+      for (int s2 = 0; s2 < MAXDEG; ++s2) {
+        const Row<K> r = cx.read_row(cx.rowoff(s2));
+        z += r.v[0];
+      }
+      acc = g + z * 1e-3;
     }
   }
   const long long t1 = __builtin_readcyclecounter();
@@ -718,7 +807,7 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     const char *e = getenv("GIK_DBG");
     a.dbg = e ? atoi(e) : 0;
     a.dbg_buf = nullptr;
-    if (a.dbg & 4) {
+    if (a.dbg & (4 | 8)) {
       static double *buf = nullptr;
       if (!buf) (void)hipMalloc((void **)&buf, 64 * 128 * 4 * sizeof(double));
       (void)hipMemset(buf, 0, 64 * 128 * 4 * sizeof(double));

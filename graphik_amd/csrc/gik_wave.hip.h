@@ -46,7 +46,11 @@ constexpr int WAVE = 64;
 #define GIK_FASTDIV 1   // 1: reciprocal-multiply for alpha/beta (<= 2 ulp), 0: IEEE division
 #endif
 #ifndef GIK_TREESUM
-#define GIK_TREESUM 1   // 1: pairwise tree for the slot sum of the Hessian-vector product
+#define GIK_TREESUM 2   // slot sum of the Hessian-vector product: 2 = interleaved fma chains,
+                        // 1 = products + pairwise tree, 0 = products + serial adds
+#endif
+#ifndef GIK_COLHV
+#define GIK_COLHV 1     // 1: column-form Hessian-vector product (one 8-byte gather per neighbour)
 #endif
 #ifndef GIK_BLOCKHV
 #define GIK_BLOCKHV 1   // 1: Hessian-vector product in block (graph-Laplacian) form
@@ -76,6 +80,38 @@ __device__ inline double readlane_f64(double v, int lane) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
+}
+
+// whole-wavefront lane shifts (GFX9 DPP wave_shr:1 / wave_shl:1): lane l reads lane l-N / l+N
+// The destination must not alias the source: the 64 lanes execute 16 per cycle, so an in-place
+// cross-row shift would read lanes the previous pass already overwrote.  The empty asm keeps
+// sources and results live at the same time, which forces distinct registers at no cost.
+template <int CTRL>
+__device__ inline double dpp_fresh_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int rlo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  const int rhi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+  asm volatile("" ::"v"(lo), "v"(hi), "v"(rlo), "v"(rhi));
+  return __hiloint2double(rhi, rlo);
+}
+// cond ? a : b as pure data flow: (m & a) | (~m & b) per 32-bit half
+__device__ inline double bit_select(bool cond, double a, double b) {
+  const unsigned m = cond ? 0xffffffffu : 0u;
+  const unsigned lo = ((unsigned)__double2loint(a) & m) | ((unsigned)__double2loint(b) & ~m);
+  const unsigned hi = ((unsigned)__double2hiint(a) & m) | ((unsigned)__double2hiint(b) & ~m);
+  return __hiloint2double((int)hi, (int)lo);
+}
+template <int N>
+__device__ inline double wave_shr(double v) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v = dpp_fresh_f64<0x138>(v);
+  return v;
+}
+template <int N>
+__device__ inline double wave_shl(double v) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v = dpp_fresh_f64<0x130>(v);
+  return v;
 }
 
 template <int CTRL, int ROW_MASK>
@@ -187,6 +223,46 @@ __device__ inline void wave_sum_n<6>(double (&v)[6]) {
   wave_sum4(v[0], v[1], v[2], v[3]);
   wave_sum4(v[4], v[5], z0, z1);
 }
+// Eight values: transposing exchanges on lane bits 5 and 4 with the gfx950 register-pair swaps
+// (v_permlane32_swap / v_permlane16_swap exchange the upper half of one register with the lower
+// half of another, so "keep one value of the pair, receive the partner's share of it" needs no
+// selects), one select exchange on bit 3, then a plain butterfly over bits 0-2 of the single
+// remaining register.  Value q ends up in the lanes with (bit5, bit4, bit3) = (q&1, q&2, q&4).
+// Measured 310 cycles against 390 for two wave_sum4 (tools/exp/reduce8.hip).
+__device__ inline void lane_swap32(double &a, double &b) {
+  unsigned al = __double2loint(a), ah = __double2hiint(a), bl = __double2loint(b), bh = __double2hiint(b);
+  const auto r = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
+  const auto s = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+  a = __hiloint2double((int)s[0], (int)r[0]);
+  b = __hiloint2double((int)s[1], (int)r[1]);
+}
+__device__ inline void lane_swap16(double &a, double &b) {
+  unsigned al = __double2loint(a), ah = __double2hiint(a), bl = __double2loint(b), bh = __double2hiint(b);
+  const auto r = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
+  const auto s = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+  a = __hiloint2double((int)s[0], (int)r[0]);
+  b = __hiloint2double((int)s[1], (int)r[1]);
+}
+template <>
+__device__ inline void wave_sum_n<8>(double (&v)[8]) {
+#pragma unroll
+  for (int q = 0; q < 8; q += 2) {
+    lane_swap32(v[q], v[q + 1]);
+    v[q] += v[q + 1];
+  }
+  lane_swap16(v[0], v[2]);
+  v[0] += v[2];
+  lane_swap16(v[4], v[6]);
+  v[4] += v[6];
+  const bool h8 = threadIdx.x & 8;
+  double w = (h8 ? v[4] : v[0]) + dpp_f64<0x128>(h8 ? v[0] : v[4]);  // row_ror:8 == lane^8
+  w += dpp_f64<0xB1>(w);   // quad_perm [1,0,3,2]
+  w += dpp_f64<0x4E>(w);   // quad_perm [2,3,0,1]
+  w += dpp_f64<0x141>(w);  // row_half_mirror
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    v[q] = readlane_f64(w, ((q & 1) ? 32 : 0) + ((q & 2) ? 16 : 0) + ((q & 4) ? 8 : 0));
+}
 #endif
 
 __device__ inline double wave_sum(double x) {
@@ -205,6 +281,31 @@ __device__ inline double frcp(double b) {
   const double e = fma(-b, r0, 1.0);
   const double r1 = fma(e, r0, r0);
   return fma(r1, e * e, r1);
+}
+
+// one Newton step on the v_rcp_f64 seed: relative error ~ e^2 + 1 ulp (e ~ 2^-26), chain of 3
+__device__ inline double frcp1(double b) {
+  const double r0 = __builtin_amdgcn_rcp(b);
+  return fma(fma(-b, r0, 1.0), r0, r0);
+}
+
+// Orthonormal basis of the vertical space at Y (k = 3).  The vertical space is spanned by
+// pk_m = Y E_m (E_m the three skew generators); their Gram matrix is
+//   M = [[a, b, c], [b, d, e], [c, e, f]]  (see proj_setup).
+// With M = L L^T,  Q = pk L^-T  has orthonormal columns, so the horizontal projector of
+// fixed_rank_psd_sym.py:91-113 becomes  Z - sum_m Q_m <Q_m, Z>  and
+// |proj Z|^2 = |Z|^2 - sum_m <Q_m, Z>^2 -- which lets one reduction per tCG iteration carry
+// everything the iteration needs (see rtr_solve_one).
+__device__ inline void vertical_basis(double a, double b, double c, double d, double e, double f,
+                                      const double (&pk)[3], double (&Q)[3]) {
+  const double i00 = 1.0 / sqrt(a);
+  const double l10 = b * i00, l20 = c * i00;
+  const double i11 = 1.0 / sqrt(fma(-l10, l10, d));
+  const double l21 = fma(-l20, l10, e) * i11;
+  const double i22 = 1.0 / sqrt(fma(-l21, l21, fma(-l20, l20, f)));
+  Q[0] = pk[0] * i00;
+  Q[1] = fma(-l10, Q[0], pk[1]) * i11;
+  Q[2] = fma(-l21, Q[1], fma(-l20, Q[0], pk[2])) * i22;
 }
 
 // ---- solver parameters handed to the kernels ----------------------------------------------
@@ -256,7 +357,9 @@ struct WaveCtx {
   int waddr[K];            // where this lane's value goes in tile 0..K-1 (double index)
   int own_off;             // this lane's node row in its own tile (double index)
   int nat_off;             // this lane's node row in tile 0 (natural component order)
-  int rowoff[MAXDEG];      // neighbour rows in this lane's tile (double index)
+  int coloff[MAXDEG];      // neighbour entry (j, comp) in tile 0 (double index)
+  int tile_delta;          // row of node j in this lane's rotated tile = coloff + tile_delta
+  __device__ inline int rowoff(int s) const { return coloff[s] + tile_delta; }
 #if GIK_BLOCKHV
   // Row of the 3x3 (2x2) Hessian block of slot s that belongs to this lane's component, rotated
   // like the tiles:  bq[s][q] = 2 a y_c y_(c+q) + c_ij [q == 0].   bsum = sum_s bq[s].
@@ -268,6 +371,7 @@ struct WaveCtx {
 #endif
   double pk[NC], pk2[NC], Pm[NC * NC];
   double G2[NC * NC];      // <pk2_q, pk2_m>, constant during one tCG solve
+  double Q[NC];            // k = 3: this lane's entries of the orthonormal vertical basis
 
   __device__ inline Row<K> read_row(int off) const {
     Row<K> r;
@@ -289,6 +393,13 @@ struct WaveCtx {
     __builtin_amdgcn_wave_barrier();
   }
 
+  // publish only the natural-order tile (all the column-form Hessian product reads)
+  __device__ inline void put1(double v) {
+    __builtin_amdgcn_wave_barrier();
+    sh_tile[waddr[0]] = v;
+    __builtin_amdgcn_wave_barrier();
+  }
+
   __device__ inline void init(int lane_, int N, double *tiles, const double *tgt,
                               const uint32_t *meta) {
     lane = lane_;
@@ -304,10 +415,11 @@ struct WaveCtx {
       waddr[t] = t * TILE + node * RS + pos;
     }
     own_off = comp * TILE + node * RS;
+    tile_delta = comp * TILE - comp;
     nat_off = node * RS;
 #pragma unroll
     for (int s = 0; s < MAXDEG; ++s) {
-      rowoff[s] = comp * TILE + meta_j(sh_meta[s * WAVE + lane]) * RS;
+      coloff[s] = meta_j(sh_meta[s * WAVE + lane]) * RS + comp;
 #if GIK_BLOCKHV
 #pragma unroll
       for (int q = 0; q < K; ++q) bq[s][q] = 0.0;
@@ -326,7 +438,7 @@ struct WaveCtx {
     double f = 0.0;
 #pragma unroll
     for (int s = 0; s < MAXDEG; ++s) {
-      const Row<K> r = read_row(rowoff[s]);
+      const Row<K> r = read_row(rowoff(s));
       double d = 0.0;
 #pragma unroll
       for (int q = 0; q < K; ++q) {
@@ -353,7 +465,7 @@ struct WaveCtx {
     double G = 0.0;
 #pragma unroll
     for (int s = 0; s < MAXDEG; ++s) {
-      const Row<K> r = read_row(rowoff[s]);
+      const Row<K> r = read_row(rowoff(s));
       double y[K];
       double d = 0.0;
 #pragma unroll
@@ -373,6 +485,10 @@ struct WaveCtx {
 #pragma unroll
       for (int q = 0; q < K; ++q) bq[s][q] = a2 * y[q];
       bq[s][0] += c;
+#if GIK_TREESUM == 2
+#pragma unroll
+      for (int q = 0; q < K; ++q) bq[s][q] *= 2.0;      // stored as +2 B_ij ...
+#endif
 #else
       const double sc = act ? 1.4142135623730951 : 0.0;  // sqrt(2 a), a in {0,1}
       cc[s] = c;
@@ -387,7 +503,13 @@ struct WaveCtx {
       double t = 0.0;
 #pragma unroll
       for (int s = 0; s < MAXDEG; ++s) t += bq[s][q];
+#if GIK_TREESUM == 2
+      bsum[q] = t;                                     // ... and bsum = +2 sum_j B_ij
+#pragma unroll
+      for (int s = 0; s < MAXDEG; ++s) bq[s][q] = -bq[s][q];
+#else
       bsum[q] = t;
+#endif
     }
 #endif
     return 2.0 * G;
@@ -396,19 +518,85 @@ struct WaveCtx {
   // ehess(Y, W) (lhess / jhess, costs.py:175-207, 39-58) with Y = last commit():
   //   H_i = 2 sum_j [ 2 a (y.w) y + c w ],  y = Y_i - Y_j,  w = W_i - W_j
   __device__ inline double ehess(double W) {
+#if GIK_COLHV && GIK_BLOCKHV && GIK_TREESUM == 2
+    // Column form.  A lone wavefront issues a DS instruction only every ~10 (b64) / ~16 (b128)
+    // cycles, so the row gathers (ds_read_b128 + ds_read_b64 per neighbour, three ds_write per
+    // vector) bound the row-form product.  Here lane (i, c) fetches only W_j[c] -- one 8-byte read
+    // per neighbour from the natural-order tile, one write -- and accumulates what its component
+    // contributes to all K outputs of node i:
+    //     p_t = sum_j B_ij[(c+t)%K][c] (W_i[c] - W_j[c]),   B symmetric => the same bq registers.
+    // The K lanes of a node then exchange the K-1 foreign partial sums with whole-wave DPP shifts:
+    //     H_(i,c) = p_0 + sum_t ( c >= t ? p_t[lane - t] : p_t[lane + K - t] ).
+    put1(W);
+    double ww[MAXDEG];
+#pragma unroll
+    for (int s = 0; s < MAXDEG; ++s) ww[s] = sh_tile[coloff[s]];
+    __builtin_amdgcn_sched_barrier(0);
+    double p[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) p[t] = bsum[t] * W;
+#pragma unroll
+    for (int s = 0; s < MAXDEG; ++s) {
+#pragma unroll
+      for (int t = 0; t < K; ++t) p[t] = fma(bq[s][t], ww[s], p[t]);
+    }
+    // bit-select (v_bfi_b32) instead of ?: -- the compiler turns a lane-dependent ?: over the two
+    // shifts into divergent branches, and a DPP move under a partial EXEC reads disabled lanes
+    double H = p[0];
+    if constexpr (K == 3) {
+      H += bit_select(comp >= 1, wave_shr<1>(p[1]), wave_shl<2>(p[1]));
+      H += bit_select(comp >= 2, wave_shr<2>(p[2]), wave_shl<1>(p[2]));
+    } else {
+      H += bit_select(comp >= 1, wave_shr<1>(p[1]), wave_shl<1>(p[1]));
+    }
+    return H;
+#else
     put(W);
     const Row<K> own = read_row(own_off);
 #if GIK_BLOCKHV
     // H_i = 2 sum_j B_ij (W_i - W_j) = 2 [ (sum_j B_ij) W_i - sum_j B_ij W_j ],  B_ij = 2a y y^T + c I
     // -- the graph-Laplacian form the reference's dense closure uses
     // (riemannian_solver.py:158-174: (A - diag(sum A)).dot(Z)); 3 fma per slot.
+#if GIK_TREESUM == 2
+    // fma chains: a dependent fp64 op issues every 8 cycles, an independent one every ~5-6, and
+    // nothing is gained by shortening the chain beyond that -- so spend no separate adds:
+    // NACC interleaved accumulators, 3 fma per slot, NACC-1 adds at the end.  bq/bsum carry the
+    // factor -2 (folded in at commit()).
+    constexpr int NACC = 3;
+    double acc[NACC];
+    // all gathers are issued up front, in the order they are consumed; the scheduling fences keep
+    // the compiler from sinking a read below the first use (which would turn the staged
+    // s_waitcnt lgkmcnt(n) into one wait for everything)
+    Row<K> rr[MAXDEG];
+#pragma unroll
+    for (int s = 0; s < MAXDEG; ++s) rr[s] = read_row(rowoff(s));
+    __builtin_amdgcn_sched_barrier(0);
+    acc[0] = bsum[0] * own.v[0];
+#pragma unroll
+    for (int q = 1; q < K; ++q) acc[0] = fma(bsum[q], own.v[q], acc[0]);
+#pragma unroll
+    for (int s = 0; s < MAXDEG; ++s) {
+      const Row<K> &r = rr[s];
+      const int a = (s + 1) % NACC;
+      if (s + 1 < NACC) {
+        acc[a] = bq[s][0] * r.v[0];
+      } else {
+        acc[a] = fma(bq[s][0], r.v[0], acc[a]);
+      }
+#pragma unroll
+      for (int q = 1; q < K; ++q) acc[a] = fma(bq[s][q], r.v[q], acc[a]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (MAXDEG + 1 >= 3) return (acc[0] + acc[1]) + acc[2];
+    else return acc[0] + acc[1];
+#else
     double t[MAXDEG + 1];
     t[MAXDEG] = -(bsum[0] * own.v[0]);
 #pragma unroll
     for (int q = 1; q < K; ++q) t[MAXDEG] = fma(-bsum[q], own.v[q], t[MAXDEG]);
 #pragma unroll
     for (int s = 0; s < MAXDEG; ++s) {
-      const Row<K> r = read_row(rowoff[s]);
+      const Row<K> r = read_row(rowoff(s));
       t[s] = bq[s][0] * r.v[0];
 #pragma unroll
       for (int q = 1; q < K; ++q) t[s] = fma(bq[s][q], r.v[q], t[s]);
@@ -427,12 +615,13 @@ struct WaveCtx {
     for (int s = 0; s < MAXDEG; ++s) acc += t[s];
     return -2.0 * acc;
 #endif
+#endif
 #else
     // two interleaved accumulators (even / odd slots) halve the dependent fma chain
     double H[2] = {0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < MAXDEG; ++s) {
-      const Row<K> r = read_row(rowoff[s]);
+      const Row<K> r = read_row(rowoff(s));
       double w[K];
 #pragma unroll
       for (int q = 0; q < K; ++q) w[q] = own.v[q] - r.v[q];
@@ -442,6 +631,7 @@ struct WaveCtx {
       H[GIK_SPLIT_ACC ? (s & 1) : 0] = fma(sd, ys[s][0], fma(cc[s], w[0], H[GIK_SPLIT_ACC ? (s & 1) : 0]));
     }
     return 2.0 * (H[0] + H[1]);
+#endif
 #endif
   }
 
@@ -482,6 +672,7 @@ struct WaveCtx {
       pk[0] = pk2[0] = am * (e1 * y0 - e0 * y1);
       pk[1] = pk2[1] = am * (e2 * y0 - e0 * y2);
       pk[2] = pk2[2] = am * (e2 * y1 - e1 * y2);
+      vertical_basis(a, b, c, d, e, f, pk, Q);
     } else {
       const double y0 = own.v[0], y1 = own.v[1];
       const double lm = lead ? 1.0 : 0.0;
@@ -530,12 +721,19 @@ struct WaveCtx {
       pk2[0] = am * (e0 * (y0 * u0 + y1 * u2) + e1 * (y0 * u1 + y1 * u3));
       Pm[0] = 1.0;
       G2[0] = wave_sum(pk2[0] * pk2[0]);
+      Q[0] = 0.0;
     }
   }
 
   // Z - Y Omega(Z)  (fixed_rank_psd_sym.py:111-113)
   __device__ inline double proj(double Z) const {
     double v[NC];
+    if constexpr (K == 3) {
+#pragma unroll
+      for (int m = 0; m < NC; ++m) v[m] = Q[m] * Z;
+      wave_sum_n<NC>(v);
+      return fma(-Q[2], v[2], fma(-Q[1], v[1], fma(-Q[0], v[0], Z)));
+    }
 #pragma unroll
     for (int m = 0; m < NC; ++m) v[m] = pk[m] * Z;
     wave_sum_n<NC>(v);
@@ -560,9 +758,13 @@ struct WaveCtx {
   // Same inner product as the literal <delta, proj(ehess(delta))>, different summation order.
   __device__ inline double hess_proj_dot(double delta, const double (&s_dpk)[NC], double &d_Hd,
                                          double (&hd_pk)[NC]) {
+    return proj_dot(ehess(delta), delta, s_dpk, d_Hd, hd_pk);
+  }
+  __device__ inline double proj_dot(double H, double delta, const double (&s_dpk)[NC], double &d_Hd,
+                                    double (&hd_pk)[NC]) {
 #if !GIK_MERGE_R12
     {
-      const double Hd = proj(ehess(delta));
+      const double Hd = proj(H);
       d_Hd = wave_sum(delta * Hd);
 #pragma unroll
       for (int m = 0; m < NC; ++m) hd_pk[m] = 0.0;
@@ -570,7 +772,6 @@ struct WaveCtx {
     }
 #endif
     constexpr int NV = (K == 3) ? NC + 1 : NC + 2;  // k=2: pk2 != pk needs <pk2, H> as well
-    const double H = ehess(delta);
     double v[NV];
 #pragma unroll
     for (int m = 0; m < NC; ++m) v[m] = pk[m] * H;
