@@ -29,6 +29,11 @@ struct RtrOut {
 // ||g||_F together with <g, pk2_m> in one reduction
 template <typename Ctx>
 __device__ inline double grad_norm_and_rho(Ctx &cx, double g, double (&rho0)[Ctx::NC]) {
+  if constexpr (Ctx::NC == 3) {   // k = 3 carries no <., pk2> recurrences
+#pragma unroll
+    for (int m = 0; m < Ctx::NC; ++m) rho0[m] = 0.0;
+    return sqrt(cx.sum1(g * g));
+  }
   double v[Ctx::NC + 1];
   v[0] = g * g;
 #pragma unroll
@@ -93,9 +98,14 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         const double target2 = target * target;
         const double Delta2 = Delta * Delta;
         double delta = -r;                         // :469
-        double e_Pe = 0.0, e_Pd = 0.0, d_Pd = r0_r0;  // :464-471 (precon = identity)
+        double e_Pe = 0.0, e_Pd2 = 0.0, d_Pd = r0_r0;  // :464-471 (precon = identity)
         double model_prev = __builtin_inf();       // model value before the last step (:485: 0)
         double eta_prev = 0.0, Heta_prev = 0.0;
+        // Drain every outstanding memory operation before the loop: a pending FLAT access (the
+        // trace stores of the outer iteration) may return out of order with LDS, and as long as
+        // the compiler has to assume one at the loop header it turns the first staged
+        // s_waitcnt lgkmcnt(n) of every Hessian product into lgkmcnt(0).
+        __builtin_amdgcn_s_waitcnt(0);
         for (j = 0; j < p.maxinner; ++j) {         // :495
           const double H = cx.ehess(delta);        // :497
           double v[8] = {cx.Q[0] * H, cx.Q[1] * H, cx.Q[2] * H,      delta * H,
@@ -106,18 +116,18 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
           const double Hd_Hd = fma(-v[2], v[2], fma(-v[1], v[1], fma(-v[0], v[0], v[5])));
           const double model_value = v[6];         // :551 evaluated at the current eta
           const double r_r = v[7];                 // :564 exact
-          const double alpha = r_r * frcp1(d_Hd);  // :503
-          const double a2 = alpha + alpha;
-          const double e_Pe_new = fma(alpha, fma(alpha, d_Pd, 2.0 * e_Pd), e_Pe);      // :506
-          double new_r_r = fma(alpha, fma(alpha, Hd_Hd, v[4] + v[4]), r_r);            // :564 predicted
+          const double rho = frcp1(d_Hd);
+          const double alpha = r_r * rho;          // :503
+          const double e_Pe_new = fma(alpha, fma(alpha, d_Pd, e_Pd2), e_Pe);           // :506
+          // <r',r'>/<r,r> = 1 + (2 <r,Hdelta> + alpha |Hdelta|^2) / <delta,Hdelta>   (alpha/<r,r> = rho)
+          const double beta_p = fma(fma(alpha, Hd_Hd, v[4] + v[4]), rho, 1.0);         // :592 predicted
+          double new_r_r = beta_p * r_r;                                               // :564 predicted
           const double new_eta = fma(alpha, delta, eta);      // :538
           const double new_Heta = fma(alpha, Hdelta, Heta);   // :542
           const double new_r = fma(alpha, Hdelta, r);         // :561
-          const double beta_p = new_r_r * frcp1(r_r);         // :592
           const bool plain = model_value < model_prev && d_Hd > 0.0 && e_Pe_new < Delta2 &&
                              beta_p >= 1e-3 && !(j >= p.mininner && new_r_r <= target2);
           double beta = beta_p;
-          (void)a2;
           if (UNI(!plain)) {   // any exit, a NaN, or the accuracy guard
             if (!(d_Hd == d_Hd) || !(new_r_r == new_r_r) || !(model_value == model_value)) {
               bad = true;
@@ -131,6 +141,7 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
               break;
             }
             if (d_Hd <= 0.0 || e_Pe_new >= Delta2) {           // :509
+              const double e_Pd = 0.5 * e_Pd2;
               const double tau = (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta2 - e_Pe))) / d_Pd;  // :514
               eta = eta + tau * delta;                          // :516
               Heta = Heta + tau * Hdelta;                       // :521
@@ -163,7 +174,7 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
           Heta = new_Heta;
           r = new_r;                                        // :561
           delta = fma(beta, delta, -r);                     // :593
-          e_Pd = beta * fma(alpha, d_Pd, e_Pd);             // :596
+          e_Pd2 = beta * fma(alpha + alpha, d_Pd, e_Pd2);   // :596 (carried as 2 <eta, delta>)
           d_Pd = fma(beta * beta, d_Pd, new_r_r);           // :597
         }
         if (!bad && j >= p.maxinner) {

@@ -422,7 +422,7 @@ struct Variant {
   lds_fn lds;
 };
 #define GIK_VARIANT(K, D) {K, D, rtr_wave_kernel<K, D>, kat_wave_kernel<K, D>, lds_bytes_of<K, D>}
-static const Variant kVariants[] = {GIK_VARIANT(3, 10), GIK_VARIANT(3, 20), GIK_VARIANT(2, 6),
+static const Variant kVariants[] = {GIK_VARIANT(3, 9),  GIK_VARIANT(3, 10), GIK_VARIANT(3, 20), GIK_VARIANT(2, 6),
                                     GIK_VARIANT(2, 16), GIK_VARIANT(2, 31)};
 
 }  // namespace gik
@@ -843,9 +843,14 @@ double gik_debug_parts(const gik_template *t, int mode, int iters) {
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   (void)hipEventRecord(e0, 0);
-  if (t->K == 3)
+  if (t->K == 3 && t->maxdeg == 9)
+    hipLaunchKernelGGL((parts_kernel<3, 9>), dim3(1), dim3(WAVE), t->smem_bytes, 0, t->d_slot_meta,
+                       t->N, t->T, mode % 100, iters, d);
+  else if (t->K == 3 && t->maxdeg == 10)
     hipLaunchKernelGGL((parts_kernel<3, 10>), dim3(1), dim3(WAVE), t->smem_bytes, 0, t->d_slot_meta,
                        t->N, t->T, mode % 100, iters, d);
+  else if (t->K == 3)
+    return -1;
   else
     hipLaunchKernelGGL((parts_kernel<2, 6>), dim3(1), dim3(WAVE), t->smem_bytes, 0, t->d_slot_meta,
                        t->N, t->T, mode % 100, iters, d);

@@ -69,11 +69,10 @@ __device__ inline int meta_owner(uint32_t m) { return (int)((m >> 26) & 1u); }
 // ---- cross-lane primitives ---------------------------------------------------------------
 template <int CTRL>
 __device__ inline double dpp_f64(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  // every lane has a valid source for the permutations used here, so `old` is never kept;
-  // passing the source itself avoids a zero-initialising v_mov per half
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  // row-local permutations with a valid source in every lane: no `old` operand, so neither a
+  // zero-initialising v_mov nor a copy of the source is needed (in-place is safe within a row)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ inline double readlane_f64(double v, int lane) {
@@ -289,6 +288,18 @@ __device__ inline double frcp1(double b) {
   return fma(fma(-b, r0, 1.0), r0, r0);
 }
 
+// 1 / sqrt(x): v_rsq_f64 seed + two Newton steps (y <- y + y (1 - x y^2) / 2), ~1 ulp; the
+// sqrt-then-divide pair it replaces is ~260 cycles for one wavefront.
+__device__ inline double frsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+  }
+  return y;
+}
+
 // Orthonormal basis of the vertical space at Y (k = 3).  The vertical space is spanned by
 // pk_m = Y E_m (E_m the three skew generators); their Gram matrix is
 //   M = [[a, b, c], [b, d, e], [c, e, f]]  (see proj_setup).
@@ -298,11 +309,11 @@ __device__ inline double frcp1(double b) {
 // everything the iteration needs (see rtr_solve_one).
 __device__ inline void vertical_basis(double a, double b, double c, double d, double e, double f,
                                       const double (&pk)[3], double (&Q)[3]) {
-  const double i00 = 1.0 / sqrt(a);
+  const double i00 = frsqrt(a);
   const double l10 = b * i00, l20 = c * i00;
-  const double i11 = 1.0 / sqrt(fma(-l10, l10, d));
+  const double i11 = frsqrt(fma(-l10, l10, d));
   const double l21 = fma(-l20, l10, e) * i11;
-  const double i22 = 1.0 / sqrt(fma(-l21, l21, fma(-l20, l20, f)));
+  const double i22 = frsqrt(fma(-l21, l21, fma(-l20, l20, f)));
   Q[0] = pk[0] * i00;
   Q[1] = fma(-l10, Q[0], pk[1]) * i11;
   Q[2] = fma(-l21, Q[1], fma(-l20, Q[0], pk[2])) * i22;
@@ -515,6 +526,20 @@ struct WaveCtx {
     return 2.0 * G;
   }
 
+  // slot s of the column-form product, with an explicit staged wait: gather s has landed once at
+  // most MAXDEG-1-s DS operations are outstanding (DS returns in order)
+  template <int S>
+  __device__ inline void hv_slots(double (&p)[K], const double (&ww)[MAXDEG]) {
+    if constexpr (S < MAXDEG) {
+      __builtin_amdgcn_s_waitcnt(0xC07F | ((MAXDEG - 1 - S) << 8));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < K; ++t) p[t] = fma(bq[S][t], ww[S], p[t]);
+      __builtin_amdgcn_sched_barrier(0);
+      hv_slots<S + 1>(p, ww);
+    }
+  }
+
   // ehess(Y, W) (lhess / jhess, costs.py:175-207, 39-58) with Y = last commit():
   //   H_i = 2 sum_j [ 2 a (y.w) y + c w ],  y = Y_i - Y_j,  w = W_i - W_j
   __device__ inline double ehess(double W) {
@@ -535,11 +560,7 @@ struct WaveCtx {
     double p[K];
 #pragma unroll
     for (int t = 0; t < K; ++t) p[t] = bsum[t] * W;
-#pragma unroll
-    for (int s = 0; s < MAXDEG; ++s) {
-#pragma unroll
-      for (int t = 0; t < K; ++t) p[t] = fma(bq[s][t], ww[s], p[t]);
-    }
+    hv_slots<0>(p, ww);
     // bit-select (v_bfi_b32) instead of ?: -- the compiler turns a lane-dependent ?: over the two
     // shifts into divergent branches, and a DPP move under a partial EXEC reads disabled lanes
     double H = p[0];

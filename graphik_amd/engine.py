@@ -91,7 +91,7 @@ class Template:
             _ffi.check(self.lib.gik_template_create(C.byref(d), C.byref(h)))
         self._h = h
         deg = np.bincount(np.concatenate([self.term_i, self.term_j]), minlength=self.N).max()
-        self.maxdeg = next((m for m in ((10, 20) if self.k == 3 else (6, 16, 31)) if m >= deg), int(deg))
+        self.maxdeg = next((m for m in ((9, 10, 20) if self.k == 3 else (6, 16, 31)) if m >= deg), int(deg))
 
     @classmethod
     def from_matrices(cls, omega, psi_L=None, psi_U=None, k=3, use_limits=True, **kw):
