@@ -168,9 +168,10 @@ def main():
                      "kernel": f"rtr_wave_kernel<{k},{prob.template.maxdeg}>", "kernel_ms": kernel_ms,
                      "kernel_share_of_step": kernel_ms / (dt_local / args.steps * 1e3),
                      "flops_per_launch": flops,
-                     "note": "fp64; the solve is LDS/register resident and bound by dependent "
-                             "fp64 VALU + cross-lane latency, not by HBM or MFMA "
-                             "(SURVEY 8(d)); peak = MI355X fp64 vector/matrix spec"},
+                     "note": "fp64; the solve is LDS/register resident and bound by the instruction "
+                             "issue rate of one wavefront per problem (and, at this batch size, by "
+                             "the slowest problem), not by HBM or MFMA (SURVEY 8(d), DESIGN 4.1); "
+                             "peak = MI355X fp64 vector/matrix spec"},
         "roofline_hbm": {"bound": "hbm", "achieved": hbm_bytes / (kernel_ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -385,6 +385,18 @@ __global__ void __launch_bounds__(WAVE) parts_kernel(const uint32_t *slot_meta, 
       acc = g + z * 1e-3;
     }
   }
+  else if (mode == 19) {
+    for (int it = 0; it < iters; ++it) acc = acc * 1e-9 + cx.cost(x + acc * 1e-12);
+  } else if (mode == 20) {
+    for (int it = 0; it < iters; ++it) acc = acc * 1e-9 + cx.commit();
+  } else if (mode == 21) {
+    for (int it = 0; it < iters; ++it) {
+      cx.proj_setup(0);
+      acc = acc * 1e-9 + cx.Q[0];
+    }
+  } else if (mode == 22) {
+    for (int it = 0; it < iters; ++it) acc = acc * 1e-9 + sqrt(cx.sum1(acc * acc + g));
+  }
   const long long t1 = __builtin_readcyclecounter();
   if (lane == 0) {
     out[0] = (double)(t1 - t0) / iters;

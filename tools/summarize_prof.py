@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""tools/summarize_prof.py -- turn the rocprofv3 CSVs of tools/profile.sh into the small summaries
+kept under profiles/ (run here after gpurun merged gpurun_out/prof back).
+
+    python tools/summarize_prof.py [round_tag]        # default r01
+
+Writes
+    profiles/<tag>_kernel_stats.csv     per-kernel durations (copy of rocprofv3 --stats)
+    profiles/<tag>_pmc_per_launch.json  every collected counter, mean per dispatch and kernel
+    profiles/hbm_traffic.json           HBM bytes per launch of the solve kernel (bench.py reads it)
+    profiles/<tag>_bench_n1.json        the bench line of the profiled command
+Counter handling follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are collected in
+separate --pmc passes, are in KiB, and FETCH_SIZE counts half the bytes on gfx950 (x2).
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(REPO, "gpurun_out", "prof")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = os.path.join(REPO, "profiles")
+os.makedirs(out, exist_ok=True)
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0]
+
+
+shutil.copy(os.path.join(P, "kt", "r1_kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats.csv"))
+
+per = defaultdict(lambda: defaultdict(list))
+for f in sorted(glob.glob(os.path.join(P, "pmc_*", "r1_counter_collection.csv"))):
+    acc = defaultdict(float)      # (dispatch, kernel, counter) -> summed over instances
+    for row in csv.DictReader(open(f)):
+        acc[(row["Dispatch_Id"], short(row["Kernel_Name"]), row["Counter_Name"])] += float(row["Counter_Value"])
+    for (_, k, c), v in acc.items():
+        if k.startswith("gik::"):
+            per[k][c].append(v)
+summary = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in sorted(per.items())}
+for k, cs in summary.items():
+    cs["_dispatches"] = len(next(iter(per[k].values())))
+json.dump(summary, open(os.path.join(out, f"{tag}_pmc_per_launch.json"), "w"), indent=1)
+
+solve = next(k for k in summary if "rtr_wave_kernel" in k)
+fetch = summary[solve]["FETCH_SIZE"] * 1024 * 2
+write = summary[solve]["WRITE_SIZE"] * 1024
+json.dump({"kernel": solve, "bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch,
+           "write_bytes": write,
+           "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, "
+                  "tools/profile.sh), bench.py --steps 2 --warmup 1, mean over the dispatches; "
+                  "FETCH_SIZE (KiB) x1024 x2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM "
+                  "section), WRITE_SIZE (KiB) x1024"},
+          open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
+
+for line in open(os.path.join(P, "kt_bench.json")):
+    if line.startswith("{"):
+        open(os.path.join(out, f"{tag}_bench_n1.json"), "w").write(line)
+
+print(open(os.path.join(out, f"{tag}_kernel_stats.csv")).read())
+s = summary[solve]
+if "SQ_INSTS_VALU" in s:
+    b = json.loads(open(os.path.join(out, f"{tag}_bench_n1.json")).read())
+    hv = b["hv_products"]["total_per_gpu"]
+    print("per tCG iteration: VALU %.1f  LDS %.1f  MFMA %.2f  SALU %.1f  wave cycles %.0f  (hv %d)" % (
+        s["SQ_INSTS_VALU"] / hv, s["SQ_INSTS_LDS"] / hv, s.get("SQ_INSTS_MFMA", 0) / hv,
+        s["SQ_INSTS_SALU"] / hv, s["SQ_WAVE_CYCLES"] / hv, hv))
+    print("VALU active / wave cycles %.2f   LDS bank conflict / LDS active %.2f" % (
+        s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"],
+        s["SQ_LDS_BANK_CONFLICT"] / max(s.get("SQ_LDS_IDX_ACTIVE", 1), 1)))
+print("HBM traffic per launch: %.2f MB (fetch %.2f, write %.2f)" % ((fetch + write) / 1e6, fetch / 1e6, write / 1e6))
