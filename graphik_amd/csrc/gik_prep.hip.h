@@ -57,12 +57,20 @@ __device__ inline void rr_pair(int n_even, int r, int m, int &p, int &q) {
 }
 
 // Cyclic Jacobi on the symmetric N x N matrix A (LDS, row stride N); V (optional) accumulates
-// the eigenvectors as columns.  cs: 2*16 doubles, pq: 16 ints of LDS scratch.
+// the eigenvectors as columns.  cs: 2*16 doubles, pq: 16 ints of LDS scratch.  At most `sweeps`
+// sweeps; stops after the first sweep in which no off-diagonal entry exceeded 1e-16 |A|_F
+// (rotations below that are skipped, so the confirming sweep is cheap; typically 6-7 sweeps).
 __device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, double *cs, int *pq,
                                   int lane) {
   const int ne = N + (N & 1), np = ne / 2;
+  double fro = 0.0;
+  if (lane < N)
+    for (int j = 0; j < N; ++j) fro = fma(A[lane * N + j], A[lane * N + j], fro);
+  const double thr = 1e-16 * sqrt(wave_sum(fro));
   for (int sw = 0; sw < sweeps; ++sw) {
+    bool rotated = false;
     for (int r = 0; r < ne - 1; ++r) {
+      bool sig = false;
       if (lane < np) {
         int p, q;
         rr_pair(ne, r, lane, p, q);
@@ -70,7 +78,8 @@ __device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, doubl
         int code = -1;
         if (q < N) {
           const double apq = A[p * N + q];
-          if (fabs(apq) > 1e-300) {
+          if (fabs(apq) > thr) {
+            sig = true;
             const double th = (A[q * N + q] - A[p * N + p]) / (2.0 * apq);
             const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
             c = 1.0 / sqrt(t * t + 1.0);
@@ -82,6 +91,8 @@ __device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, doubl
         cs[2 * lane + 1] = s;
         pq[lane] = code;
       }
+      if (__builtin_amdgcn_ballot_w64(sig) == 0ull) continue;  // nothing to rotate in this round
+      rotated = true;
       __builtin_amdgcn_wave_barrier();
       // column phase: lanes [0,N) rotate A's columns (row = lane), lanes [32,32+N) rotate V's
       for (int m = 0; m < np; ++m) {
@@ -112,6 +123,7 @@ __device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, doubl
       }
       __builtin_amdgcn_wave_barrier();
     }
+    if (!rotated) break;
   }
 }
 

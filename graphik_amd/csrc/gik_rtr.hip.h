@@ -44,7 +44,11 @@ __device__ inline double grad_norm_and_rho(Ctx &cx, double g, double (&rho0)[Ctx
   return sqrt(v[0]);
 }
 
-template <int K, typename Ctx>
+// THETA_ONE: compiled for the reference default theta = 1 (trust_region.py:92), where
+// norm_r0 ** theta needs no pow().  The generic build evaluates pow() when theta != 1; inlined, its
+// polynomial constants are hoisted to the per-problem setup and spilled to scratch by every problem
+// (measured: +15 MB of HBM writes per 4096-goal launch), so the default path must not contain it.
+template <int K, bool THETA_ONE, typename Ctx>
 __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &trace, int has_trace,
                                      int dbg, double *dbg_buf, int b, double &x, RtrOut &out) {
   const double Delta_bar = 10.0 + K;  // typicaldist (fixed_rank_psd_sym.py:71-73)
@@ -93,7 +97,7 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         // rolled-back step has cost one extra Hessian product that is not counted).
         double r = g;                              // :448
         const double r0_r0 = norm_grad * norm_grad;   // :455 (r = grad: same sum as ||grad||^2)
-        const double nr0_theta = (p.theta == 1.0) ? norm_grad : pow(norm_grad, p.theta);
+        const double nr0_theta = (THETA_ONE || p.theta == 1.0) ? norm_grad : pow(norm_grad, p.theta);
         const double target = norm_grad * fmin(nr0_theta, p.kappa);  // rhs of :572
         const double target2 = target * target;
         const double Delta2 = Delta * Delta;
@@ -191,7 +195,7 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         double e_Pe = 0.0;
         double r_r = cx.sum1(r * r);              // :455
         const double norm_r0 = sqrt(r_r);
-        const double nr0_theta = (p.theta == 1.0) ? norm_r0 : pow(norm_r0, p.theta);
+        const double nr0_theta = (THETA_ONE || p.theta == 1.0) ? norm_r0 : pow(norm_r0, p.theta);
         const double target = norm_r0 * fmin(nr0_theta, p.kappa);  // rhs of :572
         const double target2 = target * target;
         double z_r = r_r, d_Pd = r_r;              // :464-466 (precon = identity)

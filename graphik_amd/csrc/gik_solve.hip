@@ -56,7 +56,7 @@ __device__ inline void stage_lds(double *tiles, uint32_t *meta, const uint32_t *
 // counter until the batch is exhausted.  Iteration counts differ by >50x between goals and the
 // hardware hands workgroups to XCDs round-robin, so a static block->problem map leaves whole
 // XCDs idle behind a few stragglers; the queue keeps every SIMD busy until the end.
-template <int K, int MAXDEG>
+template <int K, int MAXDEG, bool THETA_ONE>
 __global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
   using Ctx = WaveCtx<K, MAXDEG>;
   extern __shared__ double smem[];
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
     double x = cx.active ? a.Y_init[(size_t)b * NK + lane] : 0.0;
 
     RtrOut ro;
-    rtr_solve_one<K>(cx, p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro);
+    rtr_solve_one<K, THETA_ONE>(cx, p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro);
     const double fx = ro.f, norm_grad = ro.gradnorm;
     const int kiter = ro.iterations, inner_total = ro.inner_total, stop = ro.stop,
               n_accept = ro.n_accept;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
     __syncthreads();
     double x = cx.active ? a.Y_init[(size_t)b * NK + cx.node * K + cx.part] : 0.0;
     RtrOut ro;
-    rtr_solve_one<K>(cx, a.p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro);
+    rtr_solve_one<K, false>(cx, a.p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro);
     if (cx.active) a.Y_out[(size_t)b * NK + cx.node * K + cx.part] = x;
     if (tid == 0) {
       gik_stats s;
@@ -429,11 +429,13 @@ static size_t lds_bytes_of(int T) {
 
 struct Variant {
   int K, maxdeg;
-  solve_fn solve;
+  solve_fn solve;        // theta == 1 (reference default)
+  solve_fn solve_theta;  // any theta
   kat_fn kat;
   lds_fn lds;
 };
-#define GIK_VARIANT(K, D) {K, D, rtr_wave_kernel<K, D>, kat_wave_kernel<K, D>, lds_bytes_of<K, D>}
+#define GIK_VARIANT(K, D) \
+  {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, kat_wave_kernel<K, D>, lds_bytes_of<K, D>}
 static const Variant kVariants[] = {GIK_VARIANT(3, 9),  GIK_VARIANT(3, 10), GIK_VARIANT(3, 20), GIK_VARIANT(2, 6),
                                     GIK_VARIANT(2, 16), GIK_VARIANT(2, 31)};
 
@@ -839,8 +841,8 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
       hipLaunchKernelGGL(rtr_block_kernel<2>, dim3(grid), dim3(BLOCK_NT), t->smem_bytes,
                          (hipStream_t)stream, a, t->SL);
   } else {
-    hipLaunchKernelGGL(t->variant->solve, dim3(grid), dim3(WAVE), t->smem_bytes,
-                       (hipStream_t)stream, a);
+    hipLaunchKernelGGL(t->p.theta == 1.0 ? t->variant->solve : t->variant->solve_theta, dim3(grid),
+                       dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
   }
   HIP_OK(hipGetLastError());
   return 0;
