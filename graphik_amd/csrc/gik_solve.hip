@@ -113,7 +113,8 @@ struct KatArgs {
   const double *Y;        // [B][N*K]
   const double *W;        // [B][N*K] (hess, proj)
   double *out;            // cost: [B]; others: [B][N*K]
-  int N, T, B, mode;      // 0 cost, 1 grad, 2 hess, 3 proj
+  double *out_f;          // mode 4: cost [B] next to the gradient in `out`
+  int N, T, B, mode;      // 0 cost, 1 grad, 2 hess, 3 proj, 4 cost and grad (one pass)
   int planar_proj_exact;
 };
 
@@ -144,6 +145,10 @@ __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
   if (a.mode == 1) {
     cx.put(y);
     res = cx.commit();
+  } else if (a.mode == 4) {
+    const double f = cx.cost(y);   // leaves the rows of y in the tiles for commit()
+    res = cx.commit();
+    if (lane == 0) a.out_f[b] = f;
   } else if (a.mode == 2) {
     cx.put(y);
     (void)cx.commit();
@@ -225,6 +230,7 @@ __global__ void __launch_bounds__(BLOCK_NT) kat_block_kernel(KatArgs a, int SL) 
     if (tid == 0) a.out[b] = f;
     return;
   }
+  if (a.mode == 4 && tid == 0) a.out_f[b] = f;
   double res = cx.commit();
   if (a.mode == 2) {
     res = cx.ehess(w);
@@ -744,12 +750,14 @@ int gik_ik_batch(const gik_template *t, const double *d_T_goal, int B, double *d
 }
 
 static int launch_kat(const gik_template *t, int mode, const double *d_Y, const double *d_W,
-                      const double *d_targets, int B, double *d_out, void *stream) {
+                      const double *d_targets, int B, double *d_out, void *stream,
+                      double *d_out_f = nullptr) {
   using namespace gik;
   if (!t || B < 0) return fail("bad argument");
   if (B == 0) return 0;
   if (!d_Y || !d_out) return fail("null buffer");
   KatArgs a;
+  a.out_f = d_out_f;
   a.slot_meta = t->d_slot_meta;
   a.targets = d_targets;
   a.Y = d_Y;
@@ -783,6 +791,12 @@ int gik_grad(const gik_template *t, const double *d_Y, const double *d_targets, 
              double *d_out, void *stream) {
   if (!d_targets) return gik::fail("targets required");
   return launch_kat(t, 1, d_Y, nullptr, d_targets, B, d_out, stream);
+}
+int gik_cost_and_grad(const gik_template *t, const double *d_Y, const double *d_targets, int B,
+                      double *d_f, double *d_grad, void *stream) {
+  if (!d_targets) return gik::fail("targets required");
+  if (B > 0 && !d_f) return gik::fail("null buffer");
+  return launch_kat(t, 4, d_Y, nullptr, d_targets, B, d_grad, stream, d_f);
 }
 int gik_hess(const gik_template *t, const double *d_Y, const double *d_W,
              const double *d_targets, int B, double *d_out, void *stream) {

@@ -156,6 +156,17 @@ class Template:
                                          self._stream()))
         return out.reshape(B, self.N, self.k)
 
+    def cost_and_grad(self, Y, targets):
+        """lcost_and_grad / jcost_and_grad (costs.py:126-169, 61-77): (f [B], G [B,N,k]) in one pass."""
+        Y, B = self._vec(Y)
+        t = self._tg(targets, B)
+        f = torch.empty(B, dtype=torch.float64, device=Y.device)
+        out = torch.empty_like(Y)
+        with torch.cuda.device(self.device):
+            _ffi.check(self.lib.gik_cost_and_grad(self._h, Y.data_ptr(), t.data_ptr(), B, f.data_ptr(),
+                                                  out.data_ptr(), self._stream()))
+        return f, out.reshape(B, self.N, self.k)
+
     def hess(self, Y, W, targets):
         Y, B = self._vec(Y)
         W, _ = self._vec(W)

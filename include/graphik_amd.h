@@ -7,6 +7,7 @@
  *   (1) the numba-AOT extension `graphik.solvers.costgrd`
  *       (graphik/solvers/costs.py:5-207, imported at graphik/solvers/riemannian_solver.py:18-21):
  *           jcost/jgrad/jhess, lcost/lgrad/lhess            -> gik_cost / gik_grad / gik_hess
+ *           jcost_and_grad (:61-77), lcost_and_grad (:126-169)       -> gik_cost_and_grad
  *   (2) the numba-jitted manifold methods
  *       (graphik/utils/manifolds/fixed_rank_psd_sym.py:75-113): proj            -> gik_proj
  *   (3) pymanopt-style `TrustRegions.solve(problem, x)` as called from
@@ -107,6 +108,9 @@ int gik_cost(const gik_template *t, const double *d_Y, const double *d_targets, 
              double *d_f, void *stream);                      /* lcost / jcost            */
 int gik_grad(const gik_template *t, const double *d_Y, const double *d_targets, int B,
              double *d_out, void *stream);                    /* lgrad / jgrad            */
+int gik_cost_and_grad(const gik_template *t, const double *d_Y, const double *d_targets, int B,
+                      double *d_f, double *d_grad, void *stream); /* lcost_and_grad / jcost_and_grad:
+                                                 one pass over the residual terms, same (f, G) */
 int gik_hess(const gik_template *t, const double *d_Y, const double *d_W,
              const double *d_targets, int B, double *d_out, void *stream); /* lhess/jhess */
 int gik_proj(const gik_template *t, const double *d_Y, const double *d_Z, int B,

@@ -56,6 +56,10 @@ def lib(fast=False):
         L.gik_o_jcost.argtypes = [_dp, _dp, _ip, _ip, C.c_int64, C.c_int, C.c_int]
         L.gik_o_jgrad.argtypes = [_dp, _dp, _ip, _ip, C.c_int64, C.c_int, C.c_int, _dp]
         L.gik_o_jhess.argtypes = [_dp, _dp, _dp, _ip, _ip, C.c_int64, C.c_int, C.c_int, _dp]
+        L.gik_o_jcost_and_grad.restype = C.c_double
+        L.gik_o_jcost_and_grad.argtypes = [_dp, _dp, _ip, _ip, C.c_int64, C.c_int, C.c_int, _dp]
+        L.gik_o_lcost_and_grad.restype = C.c_double
+        L.gik_o_lcost_and_grad.argtypes = [_dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int64, C.c_int, C.c_int, _dp]
         L.gik_o_lcost.restype = C.c_double
         L.gik_o_lcost.argtypes = [_dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int64, C.c_int, C.c_int]
         L.gik_o_lgrad.argtypes = [_dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int64, C.c_int, C.c_int,
@@ -120,6 +124,25 @@ def lgrad(Y, D_goal, omega, psi_L, psi_U, inds):
     lib().gik_o_lgrad(Y, _c(D_goal), _c(omega), _c(psi_L), _c(psi_U), ii, jj, len(ii),
                       Y.shape[0], Y.shape[1], out)
     return out
+
+
+def jcost_and_grad(Y, D_goal, inds):
+    """costs.py:61-77 -> (f, G)."""
+    ii, jj = _inds(inds)
+    Y = _c(Y)
+    out = np.empty_like(Y)
+    f = lib().gik_o_jcost_and_grad(Y, _c(D_goal), ii, jj, len(ii), Y.shape[0], Y.shape[1], out)
+    return f, out
+
+
+def lcost_and_grad(Y, D_goal, omega, psi_L, psi_U, inds):
+    """costs.py:126-169 -> (f, G)."""
+    ii, jj = _inds(inds)
+    Y = _c(Y)
+    out = np.empty_like(Y)
+    f = lib().gik_o_lcost_and_grad(Y, _c(D_goal), _c(omega), _c(psi_L), _c(psi_U), ii, jj, len(ii),
+                                   Y.shape[0], Y.shape[1], out)
+    return f, out
 
 
 def lhess(Y, w, D_goal, omega, psi_L, psi_U, inds):

@@ -80,6 +80,78 @@ void gik_o_jhess(const double *Y, const double *w, const double *D_goal, const i
   for (int t = 0; t < N * k; ++t) hess[t] *= 0.5;
 }
 
+/* costs.py:61-77   jcost_and_grad : one pass, returns (0.5 * sum 2 r^2, 0.5 * grad) */
+double gik_o_jcost_and_grad(const double *Y, const double *D_goal, const int64_t *ii,
+                            const int64_t *jj, int64_t n_inds, int N, int k, double *grad) {
+  double cost = 0.0;
+  memset(grad, 0, sizeof(double) * (size_t)N * k);
+  for (int64_t e = 0; e < n_inds; ++e) {
+    int64_t idx = ii[e], jdx = jj[e];
+    double nrm = 0.0;
+    for (int kdx = 0; kdx < k; ++kdx) {
+      double d = Y[idx * k + kdx] - Y[jdx * k + kdx];
+      nrm += d * d;
+    }
+    for (int kdx = 0; kdx < k; ++kdx) {
+      grad[idx * k + kdx] +=
+          -4.0 * (D_goal[IDX(idx, jdx, N)] - nrm) * (Y[idx * k + kdx] - Y[jdx * k + kdx]);
+      grad[jdx * k + kdx] +=
+          -4.0 * (D_goal[IDX(jdx, idx, N)] - nrm) * (Y[jdx * k + kdx] - Y[idx * k + kdx]);
+    }
+    double r = D_goal[IDX(idx, jdx, N)] - nrm;
+    cost += 2.0 * (r * r);
+  }
+  for (int t = 0; t < N * k; ++t) grad[t] *= 0.5;
+  return 0.5 * cost;
+}
+
+/* costs.py:126-169   lcost_and_grad */
+double gik_o_lcost_and_grad(const double *Y, const double *D_goal, const double *omega,
+                            const double *psi_L, const double *psi_U, const int64_t *ii,
+                            const int64_t *jj, int64_t n_inds, int N, int k, double *grad) {
+  double cost = 0.0;
+  memset(grad, 0, sizeof(double) * (size_t)N * k);
+  for (int64_t e = 0; e < n_inds; ++e) {
+    int64_t idx = ii[e], jdx = jj[e];
+    size_t ij = IDX(idx, jdx, N), ji = IDX(jdx, idx, N);
+    double nrm = 0.0;
+    for (int kdx = 0; kdx < k; ++kdx) {
+      double d = Y[idx * k + kdx] - Y[jdx * k + kdx];
+      nrm += d * d;
+    }
+    if (omega[ij] > 0) {
+      double r = D_goal[ij] - nrm;
+      cost += 2.0 * (r * r);
+      for (int kdx = 0; kdx < k; ++kdx) {
+        grad[idx * k + kdx] += 4.0 * (nrm - D_goal[ij]) * (Y[idx * k + kdx] - Y[jdx * k + kdx]);
+        grad[jdx * k + kdx] += 4.0 * (nrm - D_goal[ji]) * (Y[jdx * k + kdx] - Y[idx * k + kdx]);
+      }
+    }
+    if (psi_L[ij] > 0) {
+      double r = fmax(psi_L[ij] - nrm, 0.0);
+      cost += 2.0 * (r * r);
+      if (fmax(psi_L[ij] - nrm, 0.0) > 0) {
+        for (int kdx = 0; kdx < k; ++kdx) {
+          grad[idx * k + kdx] += 4.0 * (nrm - psi_L[ij]) * (Y[idx * k + kdx] - Y[jdx * k + kdx]);
+          grad[jdx * k + kdx] += 4.0 * (nrm - psi_L[ji]) * (Y[jdx * k + kdx] - Y[idx * k + kdx]);
+        }
+      }
+    }
+    if (psi_U[ij] > 0) {
+      double r = fmax(-psi_U[ij] + nrm, 0.0);
+      cost += 2.0 * (r * r);
+      if (fmax(-psi_U[ij] + nrm, 0.0) > 0) {
+        for (int kdx = 0; kdx < k; ++kdx) {
+          grad[idx * k + kdx] += 4.0 * (nrm - psi_U[ij]) * (Y[idx * k + kdx] - Y[jdx * k + kdx]);
+          grad[jdx * k + kdx] += 4.0 * (nrm - psi_U[ji]) * (Y[jdx * k + kdx] - Y[idx * k + kdx]);
+        }
+      }
+    }
+  }
+  for (int t = 0; t < N * k; ++t) grad[t] *= 0.5;
+  return 0.5 * cost;
+}
+
 /* costs.py:80-93   lcost */
 double gik_o_lcost(const double *Y, const double *D_goal, const double *omega,
                    const double *psi_L, const double *psi_U, const int64_t *ii,

@@ -27,6 +27,11 @@ void gik_o_jgrad(const double *Y, const double *D_goal, const int64_t *ii, const
                  int64_t n_inds, int N, int k, double *grad);         /* costs.py:20-35  */
 void gik_o_jhess(const double *Y, const double *w, const double *D_goal, const int64_t *ii,
                  const int64_t *jj, int64_t n_inds, int N, int k, double *hess); /* :39-58 */
+double gik_o_jcost_and_grad(const double *Y, const double *D_goal, const int64_t *ii,
+                            const int64_t *jj, int64_t n_inds, int N, int k, double *grad);
+double gik_o_lcost_and_grad(const double *Y, const double *D_goal, const double *omega,
+                            const double *psi_L, const double *psi_U, const int64_t *ii,
+                            const int64_t *jj, int64_t n_inds, int N, int k, double *grad);
 double gik_o_lcost(const double *Y, const double *D_goal, const double *omega,
                    const double *psi_L, const double *psi_U, const int64_t *ii,
                    const int64_t *jj, int64_t n_inds, int N, int k);  /* costs.py:80-93  */

@@ -49,6 +49,9 @@ def test_cost_grad_hess_proj_known_answers(torch_cuda, name):
     g = T.grad(Ys, tg).cpu().numpy()
     h = T.hess(Ys, Ws, tg).cpu().numpy()
     c = T.cost(Ys, tg).cpu().numpy()
+    # fused twin (lcost_and_grad / jcost_and_grad): one pass, bit-identical to the separate calls
+    cf, gf = T.cost_and_grad(Ys, tg)
+    assert np.array_equal(cf.cpu().numpy(), c) and np.array_equal(gf.cpu().numpy(), g)
     for m in range(len(Ys)):
         if use_lim:
             rc = co.lcost(Ys[m], D, om, pL, pU, inds)
