@@ -84,6 +84,7 @@ __global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
 
     for (int t = lane; t < a.T; t += WAVE) sh_tgt[t] = a.targets[(size_t)b * a.T + t];
     __builtin_amdgcn_wave_barrier();
+    cx.load_slot_records();
     double x = cx.active ? a.Y_init[(size_t)b * NK + lane] : 0.0;
 
     RtrOut ro;
@@ -134,6 +135,7 @@ __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
   __builtin_amdgcn_wave_barrier();
   Ctx cx;
   cx.init(lane, a.N, sh_tiles, sh_tgt, sh_meta);
+  cx.load_slot_records();
   const double y = cx.active ? a.Y[(size_t)b * NK + lane] : 0.0;
   const double w = (a.W && cx.active) ? a.W[(size_t)b * NK + lane] : 0.0;
   if (a.mode == 0) {
@@ -256,6 +258,7 @@ __global__ void __launch_bounds__(WAVE) parts_kernel(const uint32_t *slot_meta, 
   for (int t = lane; t < T; t += WAVE) sh_tgt[t] = 1.0 + 0.01 * t;
   Ctx cx;
   cx.init(lane, N, sh_tiles, sh_tgt, sh_meta);
+  cx.load_slot_records();
   double x = cx.active ? 0.37 * lane - 0.01 * lane * lane : 0.0;
   (void)cx.cost(x);
   double g = cx.commit();

@@ -345,10 +345,21 @@ struct WaveCtx {
   static constexpr int RS = (K == 3) ? 6 : 2;  // LDS row stride in doubles (48 B / 16 B)
   static constexpr int NC = (K == 3) ? 3 : 1;  // independent entries of the skew matrix
   static constexpr int TILE = TILE_ROWS * RS;  // doubles per rotated tile
-  // LDS carve (in doubles): K tiles | targets[T] | slot meta (MAXDEG*64 u32)
+  // Per (slot, lane) record for cost()/commit(): the residual target of the slot's term and the
+  // clamp bounds that encode its kind -- EQ (-inf, +inf), LOWER (0, +inf), UPPER (-inf, 0),
+  // padding (0, 0) -- so that with u = target - d the residual is clamp(u, lo, hi) for every kind
+  // and no metadata has to be decoded per evaluation (one ds_read_b128 per slot).
+  struct SlotRec {
+    double tg;
+    float lo, hi;
+  };
+  // LDS carve: K tiles | targets[T] | slot meta (MAXDEG*64 u32) | slot records (MAXDEG*64 x 16 B)
   __host__ __device__ static constexpr size_t lds_bytes(int T) {
     return sizeof(double) * ((size_t)K * TILE + (size_t)((T + 1) & ~1)) +
-           sizeof(uint32_t) * (size_t)MAXDEG * WAVE;
+           sizeof(uint32_t) * (size_t)MAXDEG * WAVE + sizeof(SlotRec) * (size_t)MAXDEG * WAVE;
+  }
+  __device__ static inline SlotRec *rec_base(uint32_t *meta) {
+    return reinterpret_cast<SlotRec *>(meta + MAXDEG * WAVE);
   }
 
   int lane, node, comp;
@@ -365,6 +376,7 @@ struct WaveCtx {
   double *sh_tile;         // K rotated tiles
   const double *sh_tgt;    // [T] per-problem residual targets
   const uint32_t *sh_meta; // [MAXDEG][64]
+  SlotRec *sh_rec;         // [MAXDEG][64]
   int waddr[K];            // where this lane's value goes in tile 0..K-1 (double index)
   int own_off;             // this lane's node row in its own tile (double index)
   int nat_off;             // this lane's node row in tile 0 (natural component order)
@@ -411,9 +423,26 @@ struct WaveCtx {
     __builtin_amdgcn_wave_barrier();
   }
 
+  // per problem, after the targets were staged: fill this lane's slot records
+  __device__ inline void load_slot_records() {
+    const float inf = __builtin_inff();
+#pragma unroll
+    for (int s = 0; s < MAXDEG; ++s) {
+      const uint32_t m = sh_meta[s * WAVE + lane];
+      const int kind = meta_kind(m);
+      SlotRec r;
+      r.tg = sh_tgt[meta_term(m)];
+      r.lo = (kind == GIK_TERM_EQ || kind == GIK_TERM_UPPER) ? -inf : 0.0f;
+      r.hi = (kind == GIK_TERM_EQ || kind == GIK_TERM_LOWER) ? inf : 0.0f;
+      sh_rec[s * WAVE + lane] = r;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
   __device__ inline void init(int lane_, int N, double *tiles, const double *tgt,
-                              const uint32_t *meta) {
+                              uint32_t *meta) {
     lane = lane_;
+    sh_rec = rec_base(meta);
     active = lane < N * K;
     node = active ? lane / K : (TILE_ROWS - 1);
     comp = active ? lane - node * K : 0;
@@ -443,6 +472,9 @@ struct WaveCtx {
   }
 
   // f(Yv): lcost / jcost (costs.py:80-93, 8-16).  Leaves the rows of Yv in the LDS tiles.
+  // With u = target - d every residual is clamp(u, lo, hi) (see SlotRec).  Every term sits in the
+  // slot lists of both of its nodes; the component-0 lane of each node accumulates, so each term
+  // is counted exactly twice and the total is halved (exact).
   __device__ inline double cost(double Yv) {
     put(Yv);
     const Row<K> own = read_row(own_off);
@@ -450,23 +482,18 @@ struct WaveCtx {
 #pragma unroll
     for (int s = 0; s < MAXDEG; ++s) {
       const Row<K> r = read_row(rowoff(s));
-      double d = 0.0;
+      const SlotRec rc = sh_rec[s * WAVE + lane];
+      double y = own.v[0] - r.v[0];
+      double d = y * y;
 #pragma unroll
-      for (int q = 0; q < K; ++q) {
-        const double y = own.v[q] - r.v[q];
+      for (int q = 1; q < K; ++q) {
+        y = own.v[q] - r.v[q];
         d = fma(y, y, d);
       }
-      const uint32_t m = sh_meta[s * WAVE + lane];
-      const int kind = meta_kind(m);
-      const double u = sh_tgt[meta_term(m)] - d;
-      // EQ: u^2 ; LOWER: max(u,0)^2 ; UPPER: max(-u,0)^2 ; counted once per term (owner lane)
-      const double wp = (meta_owner(m) && (kind == GIK_TERM_EQ || kind == GIK_TERM_LOWER)) ? 1.0 : 0.0;
-      const double wn = (meta_owner(m) && (kind == GIK_TERM_EQ || kind == GIK_TERM_UPPER)) ? 1.0 : 0.0;
-      const double p = fmax(u, 0.0), n = fmax(-u, 0.0);
-      f = fma(wp * p, p, f);
-      f = fma(wn * n, n, f);
+      const double cl = fmin(fmax(rc.tg - d, (double)rc.lo), (double)rc.hi);
+      f = fma(cl, cl, f);
     }
-    return wave_sum(f);
+    return 0.5 * wave_sum((active && comp == 0) ? f : 0.0);
   }
 
   // Refresh the per-slot constants at the point whose rows are in the LDS tiles and return this
@@ -484,13 +511,13 @@ struct WaveCtx {
         y[q] = own.v[q] - r.v[q];
         d = fma(y[q], y[q], d);
       }
-      const uint32_t m = sh_meta[s * WAVE + lane];
-      const int kind = meta_kind(m);
-      const double c0 = d - sh_tgt[meta_term(m)];
-      // hinge active iff psi_L - d > 0 (lower) / d - psi_U > 0 (upper); equality always
-      const bool act = (kind == GIK_TERM_EQ) || (kind == GIK_TERM_LOWER && c0 < 0.0) ||
-                       (kind == GIK_TERM_UPPER && c0 > 0.0);
-      const double c = act ? c0 : 0.0;
+      const SlotRec rc = sh_rec[s * WAVE + lane];
+      // c = d - target where the term is active, else 0: -clamp(target - d, lo, hi).  A hinge is
+      // active iff its clamped residual is non-zero (psi_L - d > 0 / d - psi_U > 0), an equality
+      // always: lo * hi = -inf only for EQ (0 * inf = NaN and 0 * 0 = 0 compare false).
+      const double cl = fmin(fmax(rc.tg - d, (double)rc.lo), (double)rc.hi);
+      const bool act = (rc.lo * rc.hi < 0.0f) || (cl != 0.0);
+      const double c = -cl;
 #if GIK_BLOCKHV
       const double a2 = act ? 2.0 * y[0] : 0.0;          // 2 a y_c, a in {0,1}
 #pragma unroll
