@@ -849,7 +849,15 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   gik_template *mt = const_cast<gik_template *>(t);  // the counter ring is the only mutable part
   a.work_counter = t->d_counters + (mt->next_counter.fetch_add(1) % kCounterRing);
   HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned int), (hipStream_t)stream));
-  const int grid = std::min(B, t->n_cu * t->waves_per_cu);
+  // Persistent waves per CU.  A wavefront that shares its SIMD runs ~20 % slower, and the batch
+  // time of a few thousand goals is the run time of its slowest problem, so small batches get one
+  // wave per SIMD; with more than ~12 problems per SIMD the throughput of two waves per SIMD wins
+  // (measured on LWA4D, kernel ms at 1 / 2 waves per SIMD: B=4096 141 / 152, B=8192 174 / 188,
+  // B=16384 231 / 209).
+  int wpc = t->waves_per_cu;
+  if (!t->is_block && wpc > 4 && (long long)B <= 12LL * 4 * t->n_cu) wpc = 4;
+  if (const char *e = getenv("GIK_WAVES_PER_CU")) wpc = std::max(1, atoi(e));  // developer override
+  const int grid = std::min(B, t->n_cu * wpc);
   if (t->is_block) {
     if (t->K == 3)
       hipLaunchKernelGGL(rtr_block_kernel<3>, dim3(grid), dim3(BLOCK_NT), t->smem_bytes,
