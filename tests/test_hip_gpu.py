@@ -238,6 +238,28 @@ def test_full_size_batch_properties(torch_cuda):
     assert 0.6 < np.median(its[:48]) / np.median(o["iterations"]) < 1.6
 
 
+def test_results_independent_of_persistent_grid(torch_cuda, monkeypatch):
+    """The solve kernel is persistent (waves claim problems from a queue); the number of resident
+    waves is a scheduling choice (one or two per SIMD, gik_solve_batch) and must not change a
+    single bit of any result."""
+    d = load_golden("lwa4d")
+    T = _template(d, maxiter=60)
+    reps = 40
+    Y0 = np.tile(d["Y_init"], (reps, 1, 1))
+    tg = np.tile(T.targets_from_D(d["D_goal"]), (reps, 1))
+    outs = []
+    for wpc in ("1", "4", "8"):
+        monkeypatch.setenv("GIK_WAVES_PER_CU", wpc)
+        r = T.solve(Y0, tg)
+        outs.append((r["x"].cpu().numpy(), r["iterations"].cpu().numpy(), r["inner_total"].cpu().numpy()))
+    monkeypatch.delenv("GIK_WAVES_PER_CU")
+    for o in outs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(outs[0], o))
+    # and every replica of a goal gives the same answer
+    x = outs[0][0].reshape(reps, -1, *outs[0][0].shape[1:])
+    assert np.array_equal(x, np.broadcast_to(x[0], x.shape))
+
+
 def test_edge_cases(torch_cuda):
     import torch
     d = load_golden("lwa4d")
