@@ -426,8 +426,8 @@ struct WaveCtx {
   // per problem, after the targets were staged: fill this lane's slot records
   __device__ inline void load_slot_records() {
     const float inf = __builtin_inff();
-#pragma unroll
-    for (int s = 0; s < MAXDEG; ++s) {
+#pragma unroll 1
+    for (int s = 0; s < MAXDEG; ++s) {   // once per problem: rolled, to keep register pressure down
       const uint32_t m = sh_meta[s * WAVE + lane];
       const int kind = meta_kind(m);
       SlotRec r;
@@ -492,6 +492,7 @@ struct WaveCtx {
       }
       const double cl = fmin(fmax(rc.tg - d, (double)rc.lo), (double)rc.hi);
       f = fma(cl, cl, f);
+      if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);  // bound the number of rows in flight
     }
     return 0.5 * wave_sum((active && comp == 0) ? f : 0.0);
   }
@@ -534,6 +535,7 @@ struct WaveCtx {
       for (int q = 0; q < K; ++q) ys[s][q] = sc * y[q];
 #endif
       G = fma(c, y[0], G);
+      if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);  // bound the number of rows in flight
     }
 #if GIK_BLOCKHV
 #pragma unroll
