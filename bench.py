@@ -178,7 +178,7 @@ def main():
                          "bytes_per_launch": hbm_bytes},
     }
     traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json")
-    if os.path.exists(traffic_file):
+    if os.path.exists(traffic_file) and args.robot == "lwa4d" and B == 4096:   # profiled workload only
         try:
             out["roofline"]["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
         except Exception:
