@@ -60,12 +60,17 @@ __device__ inline void rr_pair(int n_even, int r, int m, int &p, int &q) {
 // the eigenvectors as columns.  cs: 2*16 doubles, pq: 16 ints of LDS scratch.  At most `sweeps`
 // sweeps; stops after the first sweep in which no off-diagonal entry exceeded 1e-16 |A|_F
 // (rotations below that are skipped, so the confirming sweep is cheap; typically 6-7 sweeps).
+// Only the leading n x n block is decomposed (row stride stays N): the scatter matrix of
+// linear_projection is non-zero in its leading K x K block only (K ~ 6 of N = 18).
 __device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, double *cs, int *pq,
-                                  int lane) {
+                                  int lane, int n = -1) {
+  if (n < 0) n = N;
+  const int stride = N;
+  N = n;
   const int ne = N + (N & 1), np = ne / 2;
   double fro = 0.0;
   if (lane < N)
-    for (int j = 0; j < N; ++j) fro = fma(A[lane * N + j], A[lane * N + j], fro);
+    for (int j = 0; j < N; ++j) fro = fma(A[lane * stride + j], A[lane * stride + j], fro);
   const double thr = 1e-16 * sqrt(wave_sum(fro));
   for (int sw = 0; sw < sweeps; ++sw) {
     bool rotated = false;
@@ -77,10 +82,10 @@ __device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, doubl
         double c = 1.0, s = 0.0;
         int code = -1;
         if (q < N) {
-          const double apq = A[p * N + q];
+          const double apq = A[p * stride + q];
           if (fabs(apq) > thr) {
             sig = true;
-            const double th = (A[q * N + q] - A[p * N + p]) / (2.0 * apq);
+            const double th = (A[q * stride + q] - A[p * stride + p]) / (2.0 * apq);
             const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
             c = 1.0 / sqrt(t * t + 1.0);
             s = t * c;
@@ -103,9 +108,9 @@ __device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, doubl
         double *M = (lane < 32) ? A : V;
         const int row = lane & 31;
         if (row < N && M != nullptr) {
-          const double ap = M[row * N + p], aq = M[row * N + q];
-          M[row * N + p] = c * ap - s * aq;
-          M[row * N + q] = s * ap + c * aq;
+          const double ap = M[row * stride + p], aq = M[row * stride + q];
+          M[row * stride + p] = c * ap - s * aq;
+          M[row * stride + q] = s * ap + c * aq;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -116,9 +121,9 @@ __device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, doubl
         const int p = code & 0xff, q = code >> 8;
         const double c = cs[2 * m], s = cs[2 * m + 1];
         if (lane < N) {
-          const double ap = A[p * N + lane], aq = A[q * N + lane];
-          A[p * N + lane] = c * ap - s * aq;
-          A[q * N + lane] = s * ap + c * aq;
+          const double ap = A[p * stride + lane], aq = A[q * stride + lane];
+          A[p * stride + lane] = c * ap - s * aq;
+          A[q * stride + lane] = s * ap + c * aq;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -297,7 +302,7 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
       V[e] = (r == c) ? 1.0 : 0.0;
     }
     __builtin_amdgcn_wave_barrier();
-    jacobi_lds(A, V, N, a.sweeps, cs, pq, lane);
+    jacobi_lds(A, V, N, a.sweeps, cs, pq, lane, Kc > 1 ? Kc : 2);
     if (lane < N) ev[lane] = (lane < Kc) ? A[lane * N + lane] : -INFINITY;
     __builtin_amdgcn_wave_barrier();
     if (lane < N) {
