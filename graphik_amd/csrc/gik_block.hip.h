@@ -38,6 +38,9 @@ struct BlockCtx {
   double *sh_red;            // [2][8][BLOCK_WAVES]
   int red_buf;
   double pk[NC], pk2[NC], Pm[NC * NC], G2[NC * NC], Q[NC];
+#ifdef GIK_BLK_PROF
+  double *prof = nullptr;
+#endif
 
   __host__ __device__ static constexpr size_t lds_bytes(int T, int SL) {
     return sizeof(double) * ((size_t)3 * BLOCK_MAXN * RS + (size_t)((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES) +
@@ -170,8 +173,14 @@ struct BlockCtx {
 
   // ehess(Y, W) (lhess / jhess, costs.py:175-207, 39-58) at the committed point sh_Y
   __device__ inline double ehess(double W) {
+#ifdef GIK_BLK_PROF
+    const long long pt0 = __builtin_readcyclecounter();
+#endif
     if (active) sh_W[node * RS + part] = W;
     __syncthreads();
+#ifdef GIK_BLK_PROF
+    const long long pt1 = __builtin_readcyclecounter();
+#endif
     const int me = node < N ? node : 0;
     double yi[K], wi[K];
     row(sh_Y, me, yi);
@@ -204,6 +213,14 @@ struct BlockCtx {
       for (int q = 0; q < K; ++q) acc[q] = fma(a2s, y[q], fma(c, w[q], acc[q]));
     }
     const double H = 2.0 * quad_pick(acc);
+#ifdef GIK_BLK_PROF
+    if (prof && (tid & 63) == 0) {
+      const long long pt2 = __builtin_readcyclecounter();
+      prof[8 + 3 * wave] += (double)(pt1 - pt0);
+      prof[9 + 3 * wave] += (double)(pt2 - pt1);
+      prof[10 + 3 * wave] += 1.0;
+    }
+#endif
     return active ? H : 0.0;
   }
 

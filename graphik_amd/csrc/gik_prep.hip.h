@@ -150,7 +150,7 @@ struct PrepArgs {
 };
 
 __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const PipeConst &pc = a.pc;
   const int N = pc.N, K = pc.K, NN = N * N, lane = threadIdx.x;
   double *U = smem;            // upper bounds -> ub

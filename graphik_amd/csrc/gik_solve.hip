@@ -59,7 +59,7 @@ __device__ inline void stage_lds(double *tiles, uint32_t *meta, const uint32_t *
 template <int K, int MAXDEG, bool THETA_ONE>
 __global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
   using Ctx = WaveCtx<K, MAXDEG>;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int NK = a.N * K;
   double *sh_tiles = smem;
@@ -122,7 +122,7 @@ struct KatArgs {
 template <int K, int MAXDEG>
 __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
   using Ctx = WaveCtx<K, MAXDEG>;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   const int NK = a.N * K;
@@ -180,7 +180,9 @@ __device__ inline uint32_t *block_stage(BlockCtx<K> &cx, double *smem, const uin
 
 template <int K>
 __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL) {
-  extern __shared__ double smem[];
+  // 16-byte alignment matters: the static `sh_b` below would otherwise push the dynamic segment
+  // to offset 8, and every ds_read_b128 of a point row would be misaligned (measured 5x slower)
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ int sh_b;
   const int tid = threadIdx.x;
   const int NK = a.N * K;
@@ -197,6 +199,9 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
     __syncthreads();
     double x = cx.active ? a.Y_init[(size_t)b * NK + cx.node * K + cx.part] : 0.0;
     RtrOut ro;
+#ifdef GIK_BLK_PROF
+    cx.prof = ((a.dbg & 8) && b == 0) ? a.dbg_buf : nullptr;
+#endif
     rtr_solve_one<K, false>(cx, a.p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro);
     if (cx.active) a.Y_out[(size_t)b * NK + cx.node * K + cx.part] = x;
     if (tid == 0) {
@@ -214,7 +219,7 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
 
 template <int K>
 __global__ void __launch_bounds__(BLOCK_NT) kat_block_kernel(KatArgs a, int SL) {
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const int NK = a.N * K;
@@ -249,7 +254,7 @@ template <int K, int MAXDEG>
 __global__ void __launch_bounds__(WAVE) parts_kernel(const uint32_t *slot_meta, int N, int T, int mode,
                                                      int iters, double *out) {
   using Ctx = WaveCtx<K, MAXDEG>;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   double *sh_tiles = smem;
   double *sh_tgt = smem + K * Ctx::TILE;
