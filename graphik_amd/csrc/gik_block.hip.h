@@ -78,11 +78,16 @@ struct BlockCtx {
       for (int q = 0; q < NV; ++q) buf[q * BLOCK_WAVES + wave] = v[q];
     }
     __syncthreads();
+    // cross-wave step: lane 8q + w fetches the total of wave w for value q (one LDS read per
+    // thread), a 3-stage butterfly inside each group of 8 lanes adds the eight waves in the
+    // order ((0+1)+(2+3))+((4+5)+(6+7)), and value q is read back from lane 8q
+    static_assert(BLOCK_WAVES == 8, "butterfly below assumes 8 waves");
+    double t = (lane < NV * BLOCK_WAVES) ? buf[lane] : 0.0;
+    t += dpp_f64<0xB1>(t);   // quad_perm [1,0,3,2]
+    t += dpp_f64<0x4E>(t);   // quad_perm [2,3,0,1]
+    t += dpp_f64<0x141>(t);  // row_half_mirror
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const double *r = buf + q * BLOCK_WAVES;
-      v[q] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    }
+    for (int q = 0; q < NV; ++q) v[q] = readlane_f64(t, 8 * q);
     red_buf ^= 1;  // the next reduction writes the other buffer: one barrier per reduction
   }
   __device__ inline double sum1(double x) {
