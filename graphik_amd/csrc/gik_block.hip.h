@@ -28,7 +28,7 @@ struct BlockCtx {
   static constexpr int NC = (K == 3) ? 3 : 1;
   static constexpr int RS = 4;  // LDS row stride (doubles): 32-byte rows
 
-  int tid, lane, wave, node, part, N, SL;
+  int tid, lane, wave, node, part, N, SL, SLE;  // slots [0, SLE) hold equality terms or padding only
   bool active;       // owns an unknown: node < N && part < K
   double *sh_Y;      // [128][4] accepted point
   double *sh_P;      // [128][4] proposal (cost) / point being committed
@@ -49,7 +49,7 @@ struct BlockCtx {
 
   __device__ inline bool lead() const { return tid == 0; }
 
-  __device__ inline void init(int N_, int SL_, double *base, const uint32_t *slots_lds, int T) {
+  __device__ inline void init(int N_, int SL_, int SLE_, double *base, const uint32_t *slots_lds, int T) {
     tid = threadIdx.x;
     lane = tid & 63;
     wave = tid >> 6;
@@ -57,6 +57,7 @@ struct BlockCtx {
     part = tid & 3;
     N = N_;
     SL = SL_;
+    SLE = SLE_;
     active = node < N && part < K;
     sh_Y = base;
     sh_P = sh_Y + BLOCK_MAXN * RS;
@@ -122,8 +123,23 @@ struct BlockCtx {
     double own[K];
     row(sh_P, node < N ? node : 0, own);
     double f = 0.0;
+    // equality-only slots first (no kind decoding: 5604 of the table scene's 5612 terms), then
+    // the few slots that may hold hinge terms
 #pragma unroll 4
-    for (int s = 0; s < SL; ++s) {
+    for (int s = 0; s < SLE; ++s) {
+      const uint32_t m = sh_slots[s * BLOCK_NT + tid];
+      double r[K];
+      row(sh_P, meta_j(m), r);
+      double d = 0.0;
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        const double y = own[q] - r[q];
+        d = fma(y, y, d);
+      }
+      const double u = sh_tgt[meta_term(m)] - d;
+      f = fma(meta_owner(m) ? u : 0.0, u, f);   // padding slots are never owners
+    }
+    for (int s = SLE; s < SL; ++s) {
       const uint32_t m = sh_slots[s * BLOCK_NT + tid];
       double r[K];
       row(sh_P, meta_j(m), r);
@@ -152,7 +168,21 @@ struct BlockCtx {
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = 0.0;
 #pragma unroll 4
-    for (int s = 0; s < SL; ++s) {
+    for (int s = 0; s < SLE; ++s) {   // equality terms (padding: y = 0)
+      const uint32_t m = sh_slots[s * BLOCK_NT + tid];
+      double r[K], y[K];
+      row(sh_P, meta_j(m), r);
+      double d = 0.0;
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        y[q] = own[q] - r[q];
+        d = fma(y[q], y[q], d);
+      }
+      const double c = d - sh_tgt[meta_term(m)];
+#pragma unroll
+      for (int q = 0; q < K; ++q) acc[q] = fma(c, y[q], acc[q]);
+    }
+    for (int s = SLE; s < SL; ++s) {
       const uint32_t m = sh_slots[s * BLOCK_NT + tid];
       double r[K], y[K];
       row(sh_P, meta_j(m), r);
@@ -194,7 +224,26 @@ struct BlockCtx {
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = 0.0;
 #pragma unroll 4
-    for (int s = 0; s < SL; ++s) {
+    for (int s = 0; s < SLE; ++s) {   // equality terms: always active (padding: y = w = 0)
+      const uint32_t m = sh_slots[s * BLOCK_NT + tid];
+      const int j = meta_j(m);
+      double yj[K], wj[K], y[K], w[K];
+      row(sh_Y, j, yj);
+      row(sh_W, j, wj);
+      double d = 0.0, sd = 0.0;
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        y[q] = yi[q] - yj[q];
+        w[q] = wi[q] - wj[q];
+        d = fma(y[q], y[q], d);
+        sd = fma(y[q], w[q], sd);
+      }
+      const double c = d - sh_tgt[meta_term(m)];
+      const double a2s = sd + sd;
+#pragma unroll
+      for (int q = 0; q < K; ++q) acc[q] = fma(a2s, y[q], fma(c, w[q], acc[q]));
+    }
+    for (int s = SLE; s < SL; ++s) {
       const uint32_t m = sh_slots[s * BLOCK_NT + tid];
       const int j = meta_j(m);
       double yj[K], wj[K], y[K], w[K];

@@ -167,19 +167,19 @@ __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
 // workgroup-per-problem variants (graphs with N*k > 64)
 template <int K>
 __device__ inline uint32_t *block_stage(BlockCtx<K> &cx, double *smem, const uint32_t *g_slots, int N,
-                                        int T, int SL) {
+                                        int T, int SL, int SLE) {
   const int tid = threadIdx.x;
   for (int t = tid; t < 3 * BLOCK_MAXN * BlockCtx<K>::RS; t += BLOCK_NT) smem[t] = 0.0;
   double *tg = smem + 3 * BLOCK_MAXN * BlockCtx<K>::RS;
   uint32_t *slots = reinterpret_cast<uint32_t *>(tg + ((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES);
   for (int s = 0; s < SL; ++s) slots[s * BLOCK_NT + tid] = g_slots[s * BLOCK_NT + tid];
-  cx.init(N, SL, smem, slots, T);
+  cx.init(N, SL, SLE, smem, slots, T);
   __syncthreads();
   return slots;
 }
 
 template <int K>
-__global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL) {
+__global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL, int SLE) {
   // 16-byte alignment matters: the static `sh_b` below would otherwise push the dynamic segment
   // to offset 8, and every ds_read_b128 of a point row would be misaligned (measured 5x slower)
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
   const int tid = threadIdx.x;
   const int NK = a.N * K;
   BlockCtx<K> cx;
-  block_stage<K>(cx, smem, a.slot_meta, a.N, a.T, SL);
+  block_stage<K>(cx, smem, a.slot_meta, a.N, a.T, SL, SLE);
   double *sh_tgt = smem + 3 * BLOCK_MAXN * BlockCtx<K>::RS;
   for (;;) {
     if (tid == 0) sh_b = (int)atomicAdd(a.work_counter, 1u);
@@ -218,13 +218,13 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
 }
 
 template <int K>
-__global__ void __launch_bounds__(BLOCK_NT) kat_block_kernel(KatArgs a, int SL) {
+__global__ void __launch_bounds__(BLOCK_NT) kat_block_kernel(KatArgs a, int SL, int SLE) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const int NK = a.N * K;
   BlockCtx<K> cx;
-  block_stage<K>(cx, smem, a.slot_meta, a.N, a.T, SL);
+  block_stage<K>(cx, smem, a.slot_meta, a.N, a.T, SL, SLE);
   double *sh_tgt = smem + 3 * BLOCK_MAXN * BlockCtx<K>::RS;
   for (int t = tid; t < a.T; t += BLOCK_NT)
     sh_tgt[t] = a.targets ? a.targets[(size_t)b * a.T + t] : 0.0;
@@ -468,6 +468,7 @@ struct gik_template {
   size_t smem_bytes;
   bool is_block;  // workgroup-per-problem path
   int SL;         // slots per thread on the block path
+  int SLE;        // ... of which the first SLE hold equality terms (or padding) only
   // device pre/post-processing (gik_pipeline_attach)
   bool has_pipe;
   gik::PipeConst pc;
@@ -544,23 +545,34 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
     maxdeg = std::max(maxdeg, (int)ents[i].size());
   }
   const Variant *var = nullptr;
-  int MD = 0, SL = 0;
+  int MD = 0, SL = 0, SLE = 0;
   std::vector<uint32_t> meta;
   if (is_block) {
-    // four threads per node, a contiguous quarter of the node's terms each
-    for (int i = 0; i < N; ++i) SL = std::max(SL, ((int)ents[i].size() + 3) / 4);
-    meta.assign((size_t)SL * BLOCK_NT, 0);
+    // four threads per node, a contiguous quarter of the node's terms each; within a thread the
+    // equality terms come first (slots [0, SLE): no kind decoding in the kernels) and the hinge
+    // terms last (slots [SLE, SL)); unused slots are inert padding (own node, kind 0, not owner)
+    std::vector<std::vector<Ent>> eqs(BLOCK_NT), hinges(BLOCK_NT);
+    int max_h = 0;
     for (int tid = 0; tid < BLOCK_NT; ++tid) {
       const int node = tid >> 2, part = tid & 3;
       const int deg = node < N ? (int)ents[node].size() : 0;
       const int L = (deg + 3) / 4;
+      for (int e = part * L; e < std::min(deg, (part + 1) * L); ++e) {
+        const Ent &en = ents[node][e];
+        (en.kind == GIK_TERM_EQ ? eqs : hinges)[tid].push_back(en);
+      }
+      SLE = std::max(SLE, (int)eqs[tid].size());
+      max_h = std::max(max_h, (int)hinges[tid].size());
+    }
+    SL = SLE + max_h;
+    meta.assign((size_t)SL * BLOCK_NT, 0);
+    for (int tid = 0; tid < BLOCK_NT; ++tid) {
+      const int node = tid >> 2;
       for (int s = 0; s < SL; ++s) {
         uint32_t m = meta_pack(node < N ? node : 0, 0, 0, 0);
-        const int e = part * L + s;
-        if (s < L && e < deg) {
-          const Ent &en = ents[node][e];
-          m = meta_pack(en.j, en.term, en.kind, en.owner);
-        }
+        const std::vector<Ent> &src = s < SLE ? eqs[tid] : hinges[tid];
+        const int e = s < SLE ? s : s - SLE;
+        if (e < (int)src.size()) m = meta_pack(src[e].j, src[e].term, src[e].kind, src[e].owner);
         meta[(size_t)s * BLOCK_NT + tid] = m;
       }
     }
@@ -588,6 +600,7 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   gik_template *t = new gik_template();
   t->is_block = is_block;
   t->SL = SL;
+  t->SLE = SLE;
   t->N = N;
   t->K = d->k;
   t->T = T;
@@ -779,10 +792,10 @@ static int launch_kat(const gik_template *t, int mode, const double *d_Y, const 
   if (t->is_block) {
     if (t->K == 3)
       hipLaunchKernelGGL(kat_block_kernel<3>, dim3(B), dim3(BLOCK_NT), t->smem_bytes,
-                         (hipStream_t)stream, a, t->SL);
+                         (hipStream_t)stream, a, t->SL, t->SLE);
     else
       hipLaunchKernelGGL(kat_block_kernel<2>, dim3(B), dim3(BLOCK_NT), t->smem_bytes,
-                         (hipStream_t)stream, a, t->SL);
+                         (hipStream_t)stream, a, t->SL, t->SLE);
   } else {
     hipLaunchKernelGGL(t->variant->kat, dim3(B), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
   }
@@ -866,10 +879,10 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   if (t->is_block) {
     if (t->K == 3)
       hipLaunchKernelGGL(rtr_block_kernel<3>, dim3(grid), dim3(BLOCK_NT), t->smem_bytes,
-                         (hipStream_t)stream, a, t->SL);
+                         (hipStream_t)stream, a, t->SL, t->SLE);
     else
       hipLaunchKernelGGL(rtr_block_kernel<2>, dim3(grid), dim3(BLOCK_NT), t->smem_bytes,
-                         (hipStream_t)stream, a, t->SL);
+                         (hipStream_t)stream, a, t->SL, t->SLE);
   } else {
     hipLaunchKernelGGL(t->p.theta == 1.0 ? t->variant->solve : t->variant->solve_theta, dim3(grid),
                        dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
