@@ -48,9 +48,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4096, help="goals per GPU")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="goals per GPU (default 4096; 256 for ur10_table, whose goal assembly runs "
+                         "on the host)")
     ap.add_argument("--robot", default="lwa4d",
-                    choices=["lwa4d", "ur10", "kuka", "planar10", "planar10_halfpi"],
+                    choices=["lwa4d", "ur10", "kuka", "planar10", "planar10_halfpi", "ur10_table"],
                     help="lwa4d = BASELINE configs[1] (the bench line); the others are the parity "
                          "configs, runnable here for reference numbers")
     ap.add_argument("--seed", type=int, default=0)
@@ -77,10 +79,18 @@ def main():
                              "joint_limits_upper": list_to_variable_dict(lim),
                              "joint_limits_lower": list_to_variable_dict(-lim), "num_joints": nl})
         graph = ProblemGraphPlanar(robot)
+    elif args.robot == "ur10_table":
+        # BASELINE configs[2]: UR10 + table_environment() (N = 116, 5612 terms): the
+        # workgroup-per-problem solve kernel; goal assembly / joint recovery on the host, outside
+        # the timed region
+        from graphik_amd.utils import table_environment
+        robot, graph = load_ur10()
+        for idx, obs in enumerate(table_environment()):
+            graph.add_spherical_obstacle(f"o{idx}", obs[0], obs[1])
     else:
         robot, graph = {"lwa4d": load_schunk_lwa4d, "ur10": load_ur10, "kuka": load_kuka}[args.robot]()
     prob = BatchProblem(graph, use_limits=True, device=dev)
-    B = args.batch
+    B = args.batch or (256 if args.robot == "ur10_table" else 4096)
     N, k, T, n = graph.number_of_nodes(), graph.dim, prob.template.T, robot.n
 
     # synthetic goals: rank r draws rows [r*B, (r+1)*B) of one global stream
@@ -90,9 +100,13 @@ def main():
     Q = lb + (ub - lb) * U
     T_goal = robot.fk_batch(Q)
     tpl = prob.template
-    assert prob.device_pipeline
+    on_device = prob.device_pipeline
     Tg_dev = torch.from_numpy(T_goal).to(dev)        # inputs resident in HBM
-    bufs = tpl.alloc_ik_buffers(B)
+    if on_device:
+        bufs = tpl.alloc_ik_buffers(B)
+    else:
+        tg_h, Y0_h0 = prob.prepare(T_goal)
+        tg_dev, Y0_dev = torch.from_numpy(tg_h).to(dev), torch.from_numpy(Y0_h0).to(dev)
     torch.cuda.synchronize(dev)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -100,14 +114,16 @@ def main():
     def step(i=None):
         """goal poses -> joint angles + pose errors, entirely on the device: prepare
         (from_pose, bound smoothing, MDS init) -> RTR solve -> recover (joint_variables, FK)."""
-        targets, Y0 = tpl.prepare(Tg_dev)
+        targets, Y0 = tpl.prepare(Tg_dev) if on_device else (tg_dev, Y0_dev)
         if i is not None:
             ev0[i].record()      # all kernels are launched on torch's current stream
         res = tpl.solve(Y0, targets)
         if i is not None:
             ev1[i].record()
-        q, pe, re = tpl.recover(res["x"], Tg_dev)
-        res.update(q=q, pos_err=pe, rot_err=re, Y0=Y0)
+        if on_device:
+            q, pe, re = tpl.recover(res["x"], Tg_dev)
+            res.update(q=q, pos_err=pe, rot_err=re)
+        res.update(Y0=Y0)
         return res
 
     for _ in range(args.warmup):
@@ -123,6 +139,10 @@ def main():
     dt_local = time.perf_counter() - t0
     dt = gd.max_over_ranks(dt_local, dev)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    if not on_device:   # host post-processing, after the timed region
+        qh = prob.joint_variables(res["x"].cpu().numpy(), T_goal)
+        pe, re = prob.pose_errors(qh, T_goal)
+        res.update(pos_err=torch.from_numpy(pe).to(dev), rot_err=torch.from_numpy(re).to(dev))
 
     # single gather of the per-problem results at the end (RCCL over xGMI when N > 1)
     stats_local = torch.stack([res["pos_err"], res["rot_err"], res["iterations"].double(),
@@ -149,12 +169,15 @@ def main():
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.robot} N={N} k={k} terms={T}, {B} random goals per GPU "
-                               "(BASELINE configs[1]), reference solver defaults "
+                               "(" + ("BASELINE configs[1]" if args.robot == "lwa4d" else "parity config") + "), reference solver defaults "
                                "(mingradnorm 5e-10, maxiter 3000)",
                    "robot": args.robot, "batch_per_gpu": B, "seed": args.seed,
-                   "step": "goal poses (HBM) -> prepare kernel (goal distances, bound smoothing, "
-                           "MDS init) -> RTR solve kernel -> recover kernel (joint angles, FK "
-                           "pose error); no host work inside the timed region",
+                   "step": ("goal poses (HBM) -> prepare kernel (goal distances, bound smoothing, "
+                            "MDS init) -> RTR solve kernel -> recover kernel (joint angles, FK "
+                            "pose error); no host work inside the timed region") if on_device else
+                           ("RTR solve kernel (workgroup per problem) on targets / Y_init resident in "
+                            "HBM; goal assembly and joint recovery run on the host outside the "
+                            "timed region (N > 32)"),
                    "parallelism": f"shard{world}"},
         "median_pos_err_m": float(np.median(pos)), "median_rot_err_rad": float(np.median(rot)),
         "p90_pos_err_m": float(np.percentile(pos, 90)),
@@ -165,7 +188,8 @@ def main():
         "frac_maxiter": float(np.mean(stop == 1)),
         "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": None,
-                     "kernel": f"rtr_wave_kernel<{k},{prob.template.maxdeg}>", "kernel_ms": kernel_ms,
+                     "kernel": (f"rtr_wave_kernel<{k},{prob.template.maxdeg}>" if N * k <= 64
+                                else f"rtr_block_kernel<{k}>"), "kernel_ms": kernel_ms,
                      "kernel_share_of_step": kernel_ms / (dt_local / args.steps * 1e3),
                      "flops_per_launch": flops,
                      "note": "fp64; the solve is LDS/register resident and bound by the instruction "
