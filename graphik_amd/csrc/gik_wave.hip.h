@@ -282,7 +282,10 @@ __device__ inline double frcp(double b) {
   return fma(r1, e * e, r1);
 }
 
-// one Newton step on the v_rcp_f64 seed: relative error ~ e^2 + 1 ulp (e ~ 2^-26), chain of 3
+// one Newton step on the v_rcp_f64 seed, chain of 3.  Measured on gfx950 over 2^20 samples
+// (tools/exp/rcp_accuracy.hip): seed 4.6e-8, frcp1 2.1e-15, frcp 2.2e-16, frsqrt 1.4e-16 max
+// relative error -- frcp1 feeds alpha and beta of the tCG step, whose inner products of 54 terms
+// carry errors of the same size
 __device__ inline double frcp1(double b) {
   const double r0 = __builtin_amdgcn_rcp(b);
   return fma(fma(-b, r0, 1.0), r0, r0);
