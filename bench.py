@@ -208,7 +208,7 @@ def main():
         except Exception:
             pass
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # rank 0, single-GPU runs only
         from oracle import c_oracle as co
         cores = os.cpu_count() or 1
         ns = args.cpu_sample or min(B, max(32, 8 * cores))
