@@ -76,7 +76,8 @@ typedef struct {
   double f;            /* final cost  f(x)                                                */
   double gradnorm;     /* final ||grad||_F                                                */
   int32_t iterations;  /* outer (trust-region) iterations                                 */
-  int32_t inner_total; /* Hessian-vector products (sum over tCG calls of numit+1)         */
+  int32_t inner_total; /* tCG iterations as the reference counts them (sum of numit+1); a
+                          "model increased" exit costs one product more than it reports  */
   int32_t stop;        /* 0: gradnorm < mingradnorm, 1: maxiter, 2: NaN encountered       */
   int32_t n_accept;    /* accepted steps                                                  */
 } gik_stats;
