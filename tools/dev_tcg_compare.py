@@ -41,7 +41,9 @@ for g in (0, 3, 5, 12, 13):
         ho = lambda Y_, W: co.lhess(Y_, W, D, om, pL, pU, il)
         hg = lambda Y_, W: T1.hess(Y_, W, tg)[0].cpu().numpy()
         pg = lambda Y_, Z: T1.proj(Y_, Z)[0].cpu().numpy()
-        jo = tcg(Y, G, Delta, ho, co.proj); jg = tcg(Y, G, Delta, hg, pg)
+        jo = tcg(Y, G, 1e9, ho, co.proj); jg = tcg(Y, G, 1e9, hg, pg)
+        jhg = tcg(Y, G, 1e9, hg, co.proj); jpg = tcg(Y, G, 1e9, ho, pg)
+        print("   (no TR bound) oracle/oracle %s | GPU hess + oracle proj %s | oracle hess + GPU proj %s | GPU/GPU %s" % (jo, jhg, jpg, jg))
         r = T1.solve(Y[None], tg[None] if tg.ndim == 1 else tg, trace_cap=2)
         print("goal %2d at outer %4d (f %.1e, |g| %.1e, Delta %.1e): numpy tCG with oracle ops %s | with GPU ops %s | GPU solver numit %d stop %d (its own Delta)" % (
             g, n, o["f(x)"], np.linalg.norm(G), Delta, jo, jg, int(r["trace"]["numit"][0][0]), int(r["trace"]["stop"][0][0])))
