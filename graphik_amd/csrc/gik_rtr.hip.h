@@ -199,9 +199,7 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         const double target = norm_r0 * fmin(nr0_theta, p.kappa);  // rhs of :572
         const double target2 = target * target;
         double z_r = r_r, d_Pd = r_r;              // :464-466 (precon = identity)
-#if GIK_FASTDIV
         double inv_z_r = frcp(z_r);
-#endif
         double delta = -r;                         // :469
         double e_Pd = 0.0, model_value = 0.0;      // :471,485
         double rho_pk[Ctx::NC], s_pk[Ctx::NC], hd_pk[Ctx::NC];  // <r,pk2>, <delta,pk2>, <Hdelta,pk2>
@@ -214,11 +212,7 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
           double d_Hd;
           const double Hdelta = cx.hess_proj_dot(delta, s_pk, d_Hd, hd_pk);  // :497-500
           if (UNI(!(d_Hd == d_Hd))) { bad = true; break; }
-#if GIK_FASTDIV
           const double alpha = z_r * frcp(d_Hd);            // :503
-#else
-          const double alpha = z_r / d_Hd;                  // :503
-#endif
           const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;  // :506
           if (UNI(d_Hd <= 0.0 || e_Pe_new >= Delta * Delta)) {   // :509
             const double tau =
@@ -254,14 +248,9 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
                                              : TCG_REACHED_TARGET_SUPERLINEAR;
             break;
           }
-          const double zold_rold = z_r;                     // :587
           z_r = r_r;                                        // :589
-#if GIK_FASTDIV
           const double beta = z_r * inv_z_r;                // :592 (1/z_r_old, formed off the critical path)
           inv_z_r = frcp(z_r);
-#else
-          const double beta = z_r / zold_rold;              // :592
-#endif
           delta = -r + beta * delta;                        // :593
           if constexpr (K == 2) {                           // the same two updates seen through pk2
 #pragma unroll

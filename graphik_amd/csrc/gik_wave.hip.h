@@ -7,17 +7,21 @@
 //
 // The masked EDM cost couples node i to its graph neighbours.  Each lane walks its node's
 // residual terms ("slots", sorted by neighbour index -- the accumulation order of the
-// reference loops, costs.py:98-123,175-207) and gathers the neighbour rows of the vector being
-// differentiated from LDS.  To keep the gather free of per-lane component selects the vector
-// is published k times, tile c holding every row rotated left by c, so that lane (i,c) always
-// finds "its" component first:  tile_c[j] = (v[j][c], v[j][c+1], v[j][c+2]).  Rows are padded
-// to 48 B (k=3) so the ds_read_b128 of a 16-lane group lands on 16 distinct 16-B slots.
-// Per-slot constants that stay fixed during one truncated-CG solve (sqrt(2a)*(Y_i - Y_j),
-// rotated the same way, and the residual c_ij) live in registers; per-problem targets and the
-// slot metadata live in LDS.  HBM is touched only at problem entry/exit.
+// reference loops, costs.py:98-123,175-207).
+//   * cost / gradient (once per outer iteration) gather whole neighbour rows from LDS.  To keep
+//     that gather free of per-lane component selects the point matrix is published k times,
+//     tile c holding every row rotated left by c, so that lane (i,c) always finds "its"
+//     component first:  tile_c[j] = (v[j][c], v[j][c+1], v[j][c+2]).  Rows are 48 B (k=3).
+//   * the Hessian-vector product (every truncated-CG iteration) is in column form: lane (i,c)
+//     fetches only W_j[c] from the natural-order tile 0 and the k lanes of a node exchange their
+//     partial sums with whole-wave DPP shifts (see WaveCtx::ehess).
+// Per-slot constants that stay fixed during one truncated-CG solve (the row of the 3x3 Hessian
+// block 2a y y^T + c I that belongs to the lane) live in registers; per-problem targets, the
+// per-(slot, lane) records and the slot metadata live in LDS.  HBM is touched only at problem
+// entry/exit.
 //
 // A single wavefront executes its DS instructions in order, so a ds_write followed by
-// ds_reads of other lanes' data needs no barrier and no s_waitcnt in between.
+// ds_reads of other lanes' data needs no barrier.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -29,32 +33,6 @@ namespace gik {
 
 constexpr int WAVE = 64;
 
-// build-time experiment switches (defaults = shipped configuration)
-#ifndef GIK_XROW
-#define GIK_XROW 0      // 0: v_readlane cross-row combine, 1: row_bcast15/31
-#endif
-#ifndef GIK_MERGE_R12
-#define GIK_MERGE_R12 1 // 1: curvature <delta,Hdelta> from the projection's reduction
-#endif
-#ifndef GIK_SPLIT_ACC
-#define GIK_SPLIT_ACC 1 // 1: two interleaved accumulators in ehess
-#endif
-#ifndef GIK_TREDUCE
-#define GIK_TREDUCE 1   // 1: MFMA (v_mfma_f64_4x4x4) wave reductions, 0: DPP butterfly
-#endif
-#ifndef GIK_FASTDIV
-#define GIK_FASTDIV 1   // 1: reciprocal-multiply for alpha/beta (<= 2 ulp), 0: IEEE division
-#endif
-#ifndef GIK_TREESUM
-#define GIK_TREESUM 2   // slot sum of the Hessian-vector product: 2 = interleaved fma chains,
-                        // 1 = products + pairwise tree, 0 = products + serial adds
-#endif
-#ifndef GIK_COLHV
-#define GIK_COLHV 1     // 1: column-form Hessian-vector product (one 8-byte gather per neighbour)
-#endif
-#ifndef GIK_BLOCKHV
-#define GIK_BLOCKHV 1   // 1: Hessian-vector product in block (graph-Laplacian) form
-#endif
 constexpr int TILE_ROWS = 33;  // 32 nodes max + one dump row for idle lanes
 
 // slot metadata word: [7:0] neighbour node j, [23:8] term index, [25:24] kind, [26] owner
@@ -137,28 +115,18 @@ __device__ inline void wave_sum_n(double (&v)[NV]) {
   for (int q = 0; q < NV; ++q) v[q] += dpp_f64<0x141>(v[q]); // row_half_mirror
 #pragma unroll
   for (int q = 0; q < NV; ++q) v[q] += dpp_f64<0x140>(v[q]); // row_mirror
-#if GIK_XROW == 1
-#pragma unroll
-  for (int q = 0; q < NV; ++q) v[q] += dpp_rows_f64<0x142, 0xA>(v[q]);  // row_bcast15 -> rows 1,3
-#pragma unroll
-  for (int q = 0; q < NV; ++q) v[q] += dpp_rows_f64<0x143, 0xC>(v[q]);  // row_bcast31 -> rows 2,3
-#pragma unroll
-  for (int q = 0; q < NV; ++q) v[q] = readlane_f64(v[q], 63);
-#else
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const double r0 = readlane_f64(v[q], 0), r1 = readlane_f64(v[q], 16);
     const double r2 = readlane_f64(v[q], 32), r3 = readlane_f64(v[q], 48);
     v[q] = (r0 + r1) + (r2 + r3);
   }
-#endif
 }
 
-#if GIK_TREDUCE
 // ---- wave reductions on the matrix core ----------------------------------------------------
-// One wavefront issues a dependent fp64 VALU op only every ~28 cycles (measured), so the classic
-// 6-stage DPP butterfly (2 v_mov_dpp + 1 v_add_f64 per value and stage) costs ~350 cycles per
-// reduced value and made up 60 % of a tCG iteration.  v_mfma_f64_4x4x4 sums across lanes for
+// A lone wavefront issues an fp64 VALU op every 5-8 cycles and a DPP move every 4, so the classic
+// 6-stage DPP butterfly (2 v_mov_dpp + 1 v_add_f64 per value and stage) costs ~100 cycles per
+// reduced value plus the cross-row read-back.  v_mfma_f64_4x4x4 sums across lanes for
 // free: with B = 1 it returns  D[i][j] = sum_k A[i][k],  where on gfx950 (probed, see
 // tools/exp/mfma_layout.hip)  A[i][k] = lane (4b + i) + 16k  and  D[i][j] = lane (4b + j) + 16i
 // for the four 4-lane blocks b of a 16-lane row.  One instruction therefore adds the four rows
@@ -262,7 +230,6 @@ __device__ inline void wave_sum_n<8>(double (&v)[8]) {
   for (int q = 0; q < 8; ++q)
     v[q] = readlane_f64(w, ((q & 1) ? 32 : 0) + ((q & 2) ? 16 : 0) + ((q & 4) ? 8 : 0));
 }
-#endif
 
 __device__ inline double wave_sum(double x) {
   double v[1] = {x};
@@ -270,11 +237,9 @@ __device__ inline double wave_sum(double x) {
   return v[0];
 }
 
-// 1 / b to about one ulp with a short dependency chain: v_rcp_f64 seed (error e ~ 2^-26),
-// r1 = r0 (1 + e) and e^2 evaluated side by side, r2 = r1 (1 + e^2).  A lone wavefront waits ~28
-// cycles on every dependent fp64 op and IEEE division is a 10-deep chain, so the two divisions of
-// a tCG iteration (alpha = z_r / d_Hd, beta = z_r' / z_r) were ~20 % of its critical path.
-// GIK_FASTDIV=0 restores correctly rounded division.
+// 1 / b to about one ulp with a short dependency chain: v_rcp_f64 seed (error e ~ 4.6e-8),
+// r1 = r0 (1 + e) and e^2 evaluated side by side, r2 = r1 (1 + e^2).  IEEE division is a chain
+// of ten dependent fp64 instructions (~108 cycles for a lone wavefront); this is five.
 __device__ inline double frcp(double b) {
   const double r0 = __builtin_amdgcn_rcp(b);
   const double e = fma(-b, r0, 1.0);
@@ -386,15 +351,10 @@ struct WaveCtx {
   int coloff[MAXDEG];      // neighbour entry (j, comp) in tile 0 (double index)
   int tile_delta;          // row of node j in this lane's rotated tile = coloff + tile_delta
   __device__ inline int rowoff(int s) const { return coloff[s] + tile_delta; }
-#if GIK_BLOCKHV
   // Row of the 3x3 (2x2) Hessian block of slot s that belongs to this lane's component, rotated
   // like the tiles:  bq[s][q] = 2 a y_c y_(c+q) + c_ij [q == 0].   bsum = sum_s bq[s].
   double bq[MAXDEG][K];
   double bsum[K];
-#else
-  double ys[MAXDEG][K];    // sqrt(2 a_ij) * (Y_i - Y_j), rotated: [0] is this lane's component
-  double cc[MAXDEG];       // c_ij = sum over active residuals of (d - target)
-#endif
   double pk[NC], pk2[NC], Pm[NC * NC];
   double G2[NC * NC];      // <pk2_q, pk2_m>, constant during one tCG solve
   double Q[NC];            // k = 3: this lane's entries of the orthonormal vertical basis
@@ -413,9 +373,6 @@ struct WaveCtx {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int t = 0; t < K; ++t) sh_tile[waddr[t]] = v;
-#ifdef GIK_LDS_WAIT
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-#endif
     __builtin_amdgcn_wave_barrier();
   }
 
@@ -463,14 +420,8 @@ struct WaveCtx {
 #pragma unroll
     for (int s = 0; s < MAXDEG; ++s) {
       coloff[s] = meta_j(sh_meta[s * WAVE + lane]) * RS + comp;
-#if GIK_BLOCKHV
 #pragma unroll
       for (int q = 0; q < K; ++q) bq[s][q] = 0.0;
-#else
-      cc[s] = 0.0;
-#pragma unroll
-      for (int q = 0; q < K; ++q) ys[s][q] = 0.0;
-#endif
     }
   }
 
@@ -522,39 +473,24 @@ struct WaveCtx {
       const double cl = fmin(fmax(rc.tg - d, (double)rc.lo), (double)rc.hi);
       const bool act = (rc.lo * rc.hi < 0.0f) || (cl != 0.0);
       const double c = -cl;
-#if GIK_BLOCKHV
       const double a2 = act ? 2.0 * y[0] : 0.0;          // 2 a y_c, a in {0,1}
 #pragma unroll
       for (int q = 0; q < K; ++q) bq[s][q] = a2 * y[q];
       bq[s][0] += c;
-#if GIK_TREESUM == 2
 #pragma unroll
       for (int q = 0; q < K; ++q) bq[s][q] *= 2.0;      // stored as +2 B_ij ...
-#endif
-#else
-      const double sc = act ? 1.4142135623730951 : 0.0;  // sqrt(2 a), a in {0,1}
-      cc[s] = c;
-#pragma unroll
-      for (int q = 0; q < K; ++q) ys[s][q] = sc * y[q];
-#endif
       G = fma(c, y[0], G);
       if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);  // bound the number of rows in flight
     }
-#if GIK_BLOCKHV
 #pragma unroll
     for (int q = 0; q < K; ++q) {
       double t = 0.0;
 #pragma unroll
       for (int s = 0; s < MAXDEG; ++s) t += bq[s][q];
-#if GIK_TREESUM == 2
       bsum[q] = t;                                     // ... and bsum = +2 sum_j B_ij
 #pragma unroll
       for (int s = 0; s < MAXDEG; ++s) bq[s][q] = -bq[s][q];
-#else
-      bsum[q] = t;
-#endif
     }
-#endif
     return 2.0 * G;
   }
 
@@ -575,7 +511,6 @@ struct WaveCtx {
   // ehess(Y, W) (lhess / jhess, costs.py:175-207, 39-58) with Y = last commit():
   //   H_i = 2 sum_j [ 2 a (y.w) y + c w ],  y = Y_i - Y_j,  w = W_i - W_j
   __device__ inline double ehess(double W) {
-#if GIK_COLHV && GIK_BLOCKHV && GIK_TREESUM == 2
     // Column form.  A lone wavefront issues a DS instruction only every ~10 (b64) / ~16 (b128)
     // cycles, so the row gathers (ds_read_b128 + ds_read_b64 per neighbour, three ds_write per
     // vector) bound the row-form product.  Here lane (i, c) fetches only W_j[c] -- one 8-byte read
@@ -603,89 +538,6 @@ struct WaveCtx {
       H += bit_select(comp >= 1, wave_shr<1>(p[1]), wave_shl<1>(p[1]));
     }
     return H;
-#else
-    put(W);
-    const Row<K> own = read_row(own_off);
-#if GIK_BLOCKHV
-    // H_i = 2 sum_j B_ij (W_i - W_j) = 2 [ (sum_j B_ij) W_i - sum_j B_ij W_j ],  B_ij = 2a y y^T + c I
-    // -- the graph-Laplacian form the reference's dense closure uses
-    // (riemannian_solver.py:158-174: (A - diag(sum A)).dot(Z)); 3 fma per slot.
-#if GIK_TREESUM == 2
-    // fma chains: a dependent fp64 op issues every 8 cycles, an independent one every ~5-6, and
-    // nothing is gained by shortening the chain beyond that -- so spend no separate adds:
-    // NACC interleaved accumulators, 3 fma per slot, NACC-1 adds at the end.  bq/bsum carry the
-    // factor -2 (folded in at commit()).
-    constexpr int NACC = 3;
-    double acc[NACC];
-    // all gathers are issued up front, in the order they are consumed; the scheduling fences keep
-    // the compiler from sinking a read below the first use (which would turn the staged
-    // s_waitcnt lgkmcnt(n) into one wait for everything)
-    Row<K> rr[MAXDEG];
-#pragma unroll
-    for (int s = 0; s < MAXDEG; ++s) rr[s] = read_row(rowoff(s));
-    __builtin_amdgcn_sched_barrier(0);
-    acc[0] = bsum[0] * own.v[0];
-#pragma unroll
-    for (int q = 1; q < K; ++q) acc[0] = fma(bsum[q], own.v[q], acc[0]);
-#pragma unroll
-    for (int s = 0; s < MAXDEG; ++s) {
-      const Row<K> &r = rr[s];
-      const int a = (s + 1) % NACC;
-      if (s + 1 < NACC) {
-        acc[a] = bq[s][0] * r.v[0];
-      } else {
-        acc[a] = fma(bq[s][0], r.v[0], acc[a]);
-      }
-#pragma unroll
-      for (int q = 1; q < K; ++q) acc[a] = fma(bq[s][q], r.v[q], acc[a]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (MAXDEG + 1 >= 3) return (acc[0] + acc[1]) + acc[2];
-    else return acc[0] + acc[1];
-#else
-    double t[MAXDEG + 1];
-    t[MAXDEG] = -(bsum[0] * own.v[0]);
-#pragma unroll
-    for (int q = 1; q < K; ++q) t[MAXDEG] = fma(-bsum[q], own.v[q], t[MAXDEG]);
-#pragma unroll
-    for (int s = 0; s < MAXDEG; ++s) {
-      const Row<K> r = read_row(rowoff(s));
-      t[s] = bq[s][0] * r.v[0];
-#pragma unroll
-      for (int q = 1; q < K; ++q) t[s] = fma(bq[s][q], r.v[q], t[s]);
-    }
-#if GIK_TREESUM
-    // pairwise tree: a lone wavefront needs ~28 cycles per DEPENDENT fp64 add
-#pragma unroll
-    for (int w = 1; w <= MAXDEG; w *= 2) {
-#pragma unroll
-      for (int s = 0; s + w <= MAXDEG; s += 2 * w) t[s] += t[s + w];
-    }
-    return -2.0 * t[0];
-#else
-    double acc = t[MAXDEG];
-#pragma unroll
-    for (int s = 0; s < MAXDEG; ++s) acc += t[s];
-    return -2.0 * acc;
-#endif
-#endif
-#else
-    // two interleaved accumulators (even / odd slots) halve the dependent fma chain
-    double H[2] = {0.0, 0.0};
-#pragma unroll
-    for (int s = 0; s < MAXDEG; ++s) {
-      const Row<K> r = read_row(rowoff(s));
-      double w[K];
-#pragma unroll
-      for (int q = 0; q < K; ++q) w[q] = own.v[q] - r.v[q];
-      double sd = ys[s][0] * w[0];
-#pragma unroll
-      for (int q = 1; q < K; ++q) sd = fma(ys[s][q], w[q], sd);
-      H[GIK_SPLIT_ACC ? (s & 1) : 0] = fma(sd, ys[s][0], fma(cc[s], w[0], H[GIK_SPLIT_ACC ? (s & 1) : 0]));
-    }
-    return 2.0 * (H[0] + H[1]);
-#endif
-#endif
   }
 
   // Factor the horizontal-space projector at the point whose rows are in the LDS tiles
@@ -815,15 +667,6 @@ struct WaveCtx {
   }
   __device__ inline double proj_dot(double H, double delta, const double (&s_dpk)[NC], double &d_Hd,
                                     double (&hd_pk)[NC]) {
-#if !GIK_MERGE_R12
-    {
-      const double Hd = proj(H);
-      d_Hd = wave_sum(delta * Hd);
-#pragma unroll
-      for (int m = 0; m < NC; ++m) hd_pk[m] = 0.0;
-      return Hd;
-    }
-#endif
     constexpr int NV = (K == 3) ? NC + 1 : NC + 2;  // k=2: pk2 != pk needs <pk2, H> as well
     double v[NV];
 #pragma unroll
