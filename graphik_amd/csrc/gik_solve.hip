@@ -399,6 +399,17 @@ __global__ void __launch_bounds__(WAVE) parts_kernel(const uint32_t *slot_meta, 
       acc = g + z * 1e-3;
     }
   }
+  else if (mode == 23) {
+    for (int it = 0; it < iters; ++it) {     // 1-value reduction, pure DPP butterfly
+      double t = acc;
+      t += dpp_f64<0xB1>(t);
+      t += dpp_f64<0x4E>(t);
+      t += dpp_f64<0x141>(t);
+      t += dpp_f64<0x140>(t);
+      const double r0 = readlane_f64(t, 0), r1 = readlane_f64(t, 16), r2 = readlane_f64(t, 32), r3 = readlane_f64(t, 48);
+      acc = g + 1e-3 * ((r0 + r1) + (r2 + r3));
+    }
+  }
   else if (mode == 19) {
     for (int it = 0; it < iters; ++it) acc = acc * 1e-9 + cx.cost(x + acc * 1e-12);
   } else if (mode == 20) {
