@@ -532,7 +532,7 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   if (!d || !out) return fail("null argument");
   if (d->abi_version != GIK_ABI_VERSION) return fail("ABI version mismatch");
   if (d->k != 2 && d->k != 3) return fail("k must be 2 or 3");
-  const bool is_block = d->N * d->k > WAVE || d->N > 32 || d->force_block_path != 0;
+  bool is_block = d->N * d->k > WAVE || d->N > 32 || d->force_block_path != 0;
   if (d->N < 2 || d->N > BLOCK_MAXN) return fail("N must be in [2, 128]");
   if (d->n_terms < 1 || d->n_terms > 65535) return fail("n_terms out of range");
   const int N = d->N, T = d->n_terms;
@@ -558,6 +558,11 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   const Variant *var = nullptr;
   int MD = 0, SL = 0, SLE = 0;
   std::vector<uint32_t> meta;
+  if (!is_block) {   // smallest compiled slot count that holds the busiest node
+    for (const Variant &v : kVariants)
+      if (v.K == d->k && v.maxdeg >= maxdeg && (!var || v.maxdeg < var->maxdeg)) var = &v;
+    if (!var) is_block = true;   // a node busier than any wave variant: workgroup-per-problem path
+  }
   if (is_block) {
     // four threads per node, a contiguous quarter of the node's terms each; within a thread the
     // equality terms come first (slots [0, SLE): no kind decoding in the kernels) and the hinge
@@ -588,9 +593,6 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
       }
     }
   } else {
-  for (const Variant &v : kVariants)
-    if (v.K == d->k && v.maxdeg >= maxdeg && (!var || v.maxdeg < var->maxdeg)) var = &v;
-  if (!var) return fail("node degree exceeds the largest compiled slot count");
   MD = var->maxdeg;
   meta.assign((size_t)MD * WAVE, 0);
   for (int lane = 0; lane < WAVE; ++lane) {

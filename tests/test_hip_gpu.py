@@ -445,6 +445,43 @@ def test_block_path_trajectories_match_wave_path(torch_cuda, name):
     assert np.array_equal(fw < 1e-9, fb < 1e-9)
 
 
+def test_busy_nodes_fall_back_to_block_path(torch_cuda):
+    """A graph that fits a wavefront (N*k <= 64) but whose busiest node carries more residual
+    terms than the largest compiled slot count is solved by the workgroup-per-problem kernels
+    instead of being refused: planar, 20 points, an equality on every pair of neighbours and a
+    lower + upper hinge on every other pair (up to 2 * 17 + 2 terms per node > 31)."""
+    from oracle import c_oracle as co
+    from graphik_amd.engine import Template
+    rng = np.random.RandomState(7)
+    N = 20
+    P = rng.randn(N, 2) * 2.0
+    Dtrue = ((P[:, None] - P[None]) ** 2).sum(-1)
+    om = np.zeros((N, N)); pL = np.zeros((N, N)); pU = np.zeros((N, N))
+    for i in range(N):
+        for j in range(i + 1, N):
+            if j - i <= 1:
+                om[i, j] = om[j, i] = 1.0
+            else:
+                pL[i, j] = pL[j, i] = 0.5 * Dtrue[i, j]
+                pU[i, j] = pU[j, i] = 1.5 * Dtrue[i, j]
+    T = Template.from_matrices(om, pL, pU, k=2, use_limits=True)
+    assert T.maxdeg > 31
+    il = co.limit_inds(om, pL, pU)
+    D = Dtrue * om
+    tg = T.targets_from_D(D)
+    Y = P + 0.8 * rng.randn(N, 2)       # hinges partly active
+    W = rng.randn(N, 2)
+    assert rel_err(float(T.cost(Y, tg)[0]), co.lcost(Y, D, om, pL, pU, il)) < 1e-12
+    assert rel_err(T.grad(Y, tg)[0].cpu().numpy(), co.lgrad(Y, D, om, pL, pU, il)) < 1e-12
+    assert rel_err(T.hess(Y, W, tg)[0].cpu().numpy(), co.lhess(Y, W, D, om, pL, pU, il)) < 1e-12
+    r = T.solve(Y[None], tg[None] if tg.ndim == 1 else tg, trace_cap=8)
+    o = co.rtr_solve(Y, D, om, pL, pU, True, traj_cap=8)
+    m = 4
+    assert np.array_equal(r["trace"]["numit"][0][:m].cpu().numpy(), o["traj"]["numit"][:m])
+    assert np.array_equal(r["trace"]["stop"][0][:m].cpu().numpy(), o["traj"]["stop"][:m])
+    assert float(r["f"][0]) < 1e-9 and int(r["stop"][0]) == 0
+
+
 def test_ur10_table_solve(torch_cuda):
     """BASELINE configs[2]: the captured goal, from the reference's own Y_init: trajectory prefix
     against the oracle, convergence, and the EE error of the recovered configuration."""
