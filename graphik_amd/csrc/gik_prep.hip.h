@@ -85,9 +85,13 @@ __device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, doubl
           const double apq = A[p * stride + q];
           if (fabs(apq) > thr) {
             sig = true;
-            const double th = (A[q * stride + q] - A[p * stride + p]) / (2.0 * apq);
-            const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-            c = 1.0 / sqrt(t * t + 1.0);
+            // t = sgn(th) / (|th| + sqrt(th^2 + 1)), c = 1 / sqrt(t^2 + 1), s = t c  with
+            // reciprocal / reciprocal-square-root Newton steps (~1 ulp; Jacobi is self-correcting)
+            // instead of two IEEE square roots and two divisions per rotation
+            const double th = (A[q * stride + q] - A[p * stride + p]) * (0.5 * frcp(apq));
+            const double h2 = fma(th, th, 1.0);
+            const double t = (th >= 0.0 ? 1.0 : -1.0) * frcp(fabs(th) + h2 * frsqrt(h2));
+            c = frsqrt(fma(t, t, 1.0));
             s = t * c;
             code = p | (q << 8);
           }
@@ -99,31 +103,41 @@ __device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, doubl
       if (__builtin_amdgcn_ballot_w64(sig) == 0ull) continue;  // nothing to rotate in this round
       rotated = true;
       __builtin_amdgcn_wave_barrier();
-      // column phase: lanes [0,N) rotate A's columns (row = lane), lanes [32,32+N) rotate V's
-      for (int m = 0; m < np; ++m) {
-        const int code = pq[m];
-        if (code < 0) continue;
-        const int p = code & 0xff, q = code >> 8;
-        const double c = cs[2 * m], s = cs[2 * m + 1];
+      // The rotations of a round touch disjoint index pairs, so several are applied at once:
+      // the wavefront is cut into groups of GW lanes (GW = 16 if the matrix has at most 16 rows,
+      // else 32), each group takes one rotation per step and its lanes take the rows / columns.
+      const int gsh = (N <= 16) ? 4 : 5, GW = 1 << gsh, idx = lane & (GW - 1);
+      // column phase: the lower half of the wave rotates A's columns, the upper half V's
+      {
+        const int half_groups = 32 >> gsh;                 // groups per matrix: 2 or 1
+        const int grp = (lane & 31) >> gsh;
         double *M = (lane < 32) ? A : V;
-        const int row = lane & 31;
-        if (row < N && M != nullptr) {
-          const double ap = M[row * stride + p], aq = M[row * stride + q];
-          M[row * stride + p] = c * ap - s * aq;
-          M[row * stride + q] = s * ap + c * aq;
+        for (int m0 = 0; m0 < np; m0 += half_groups) {
+          const int m = m0 + grp;
+          const int code = (m < np) ? pq[m] : -1;
+          if (code >= 0 && idx < N && M != nullptr) {
+            const int p = code & 0xff, q = code >> 8;
+            const double c = cs[2 * m], s = cs[2 * m + 1];
+            const double ap = M[idx * stride + p], aq = M[idx * stride + q];
+            M[idx * stride + p] = c * ap - s * aq;
+            M[idx * stride + q] = s * ap + c * aq;
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
-      // row phase on A (column = lane)
-      for (int m = 0; m < np; ++m) {
-        const int code = pq[m];
-        if (code < 0) continue;
-        const int p = code & 0xff, q = code >> 8;
-        const double c = cs[2 * m], s = cs[2 * m + 1];
-        if (lane < N) {
-          const double ap = A[p * stride + lane], aq = A[q * stride + lane];
-          A[p * stride + lane] = c * ap - s * aq;
-          A[q * stride + lane] = s * ap + c * aq;
+      // row phase on A: all 64 lanes, 64 / GW rotations per step, lanes take the columns
+      {
+        const int groups = 64 >> gsh, grp = lane >> gsh;   // 4 or 2
+        for (int m0 = 0; m0 < np; m0 += groups) {
+          const int m = m0 + grp;
+          const int code = (m < np) ? pq[m] : -1;
+          if (code >= 0 && idx < N) {
+            const int p = code & 0xff, q = code >> 8;
+            const double c = cs[2 * m], s = cs[2 * m + 1];
+            const double ap = A[p * stride + idx], aq = A[q * stride + idx];
+            A[p * stride + idx] = c * ap - s * aq;
+            A[q * stride + idx] = s * ap + c * aq;
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
