@@ -171,3 +171,17 @@ def test_urdf_reader_reproduces_packaged_constants(name, urdf):
     n = u.n_q_joints
     r = u.make_Revolute3d(np.pi * np.ones(n), -np.pi * np.ones(n))
     assert np.abs(r.T0_array() - load_golden(name)["T0"]).max() < 1e-12
+
+
+def test_bench_algorithmic_work_matches_survey():
+    """bench.py's roofline figures use SURVEY 8(d)'s per-unit work: F_hv = 4383 flop per
+    Hessian-vector product and 1496 B of HBM traffic per solve for LWA4D (N=18, k=3, 75 terms)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.algorithmic_flops(18, 3, 75, 1, 0, 0) == 4383
+    assert bench.algorithmic_flops(13, 2, 19, 1, 0, 0) == 1116      # planar chain, C5
+    assert bench.algorithmic_bytes(18, 3, 75) == 8 * (75 + 2 * 54) + 32
