@@ -29,10 +29,12 @@ struct RtrOut {
 // ||g||_F together with <g, pk2_m> in one reduction
 template <typename Ctx>
 __device__ inline double grad_norm_and_rho(Ctx &cx, double g, double (&rho0)[Ctx::NC]) {
-  if constexpr (Ctx::NC == 3) {   // k = 3 carries no <., pk2> recurrences
+  if constexpr (Ctx::NC == 3) {   // k = 3: the components of g along the orthonormal vertical basis
+    double v[4] = {g * g, g * cx.Q[0], g * cx.Q[1], g * cx.Q[2]};
+    cx.template sum_n<4>(v);
 #pragma unroll
-    for (int m = 0; m < Ctx::NC; ++m) rho0[m] = 0.0;
-    return sqrt(cx.sum1(g * g));
+    for (int m = 0; m < 3; ++m) rho0[m] = v[m + 1];
+    return sqrt(v[0]);
   }
   double v[Ctx::NC + 1];
   v[0] = g * g;
@@ -74,11 +76,10 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
       int j = 0;
       const long long prof_t1 = prof ? (long long)__builtin_readcyclecounter() : 0;
       if constexpr (K == 3) {
-        // One reduction per inner iteration.  All tangent vectors of the recurrences are
-        // horizontal (the Euclidean gradient of a rotation-invariant cost is, and every Hdelta is
-        // projected), the raw Hessian is symmetric and the projector P = I - Q Q^T is orthogonal,
-        // so with H = ehess(delta), u = Q^T H, Hdelta = H - Q u:
-        //     <delta, Hdelta> = <delta, H>     <r, Hdelta> = <r, H>     |Hdelta|^2 = |H|^2 - u.u
+        // One reduction per inner iteration.  The projector P = I - Q Q^T is orthogonal, so for
+        // HORIZONTAL delta and w (= -P r, see below), with H = ehess(delta), u = Q^T H,
+        // Hdelta = H - Q u:
+        //     <delta, Hdelta> = <delta, H>     <r, Hdelta> = -<w, H>     |Hdelta|^2 = |H|^2 - u.u
         // Everything the textbook loop reduces AFTER its vector updates is either predicted from
         // these, or reduced one iteration late next to them:
         //   * <r', r'> = <r, r> + 2 alpha <r, Hdelta> + alpha^2 |Hdelta|^2 gives beta (:592) and
@@ -101,7 +102,17 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         const double target = norm_grad * fmin(nr0_theta, p.kappa);  // rhs of :572
         const double target2 = target * target;
         const double Delta2 = Delta * Delta;
-        double delta = -r;                         // :469
+        // w = -(horizontal part of r).  The reference never projects the gradient
+        // (fixed_rank_psd_sym.py:123-124), so r carries the vertical round-off of egrad for the
+        // whole solve (every Hdelta is horizontal) and delta = -r + beta delta accumulates it.  Its
+        // <delta, Hdelta> (:500) does not see that part -- Hdelta is projected -- but <delta, H>
+        // with the raw H would, and late in a solve, where |r| falls to the size of that round-off,
+        // the difference keeps tCG from ever leaving through the model test (measured on UR10:
+        // one solve in five ran a 10000-iteration tCG the reference ends after ~150).  So delta
+        // is built from w, which follows the same recurrence as -r from a projected start, and the
+        // identities above hold to rounding; r itself, <r, r>, alpha and beta stay the reference's.
+        double w = fma(rho0[2], cx.Q[2], fma(rho0[1], cx.Q[1], fma(rho0[0], cx.Q[0], -g)));
+        double delta = w;                          // :469 (horizontal part)
         double e_Pe = 0.0, e_Pd2 = 0.0, d_Pd = r0_r0;  // :464-471 (precon = identity)
         double model_prev = __builtin_inf();       // model value before the last step (:485: 0)
         double eta_prev = 0.0, Heta_prev = 0.0;
@@ -113,7 +124,7 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         for (j = 0; j < p.maxinner; ++j) {         // :495
           const double H = cx.ehess(delta);        // :497
           double v[8] = {cx.Q[0] * H, cx.Q[1] * H, cx.Q[2] * H,      delta * H,
-                         r * H,       H * H,       eta * fma(0.5, Heta, g), r * r};
+                         w * H,       H * H,       eta * fma(0.5, Heta, g), r * r};
           cx.template sum_n<8>(v);
           const double Hdelta = fma(-cx.Q[2], v[2], fma(-cx.Q[1], v[1], fma(-cx.Q[0], v[0], H)));
           const double d_Hd = v[3];                // :500
@@ -122,13 +133,25 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
           const double r_r = v[7];                 // :564 exact
           const double rho = frcp1(d_Hd);
           const double alpha = r_r * rho;          // :503
+#ifdef GIK_TCGDUMP
+          if ((dbg & 4) && b == 0 && dbg_buf && kiter == 0) {
+            const int slot = j < 256 ? j : 256 + (j >> 5);
+            const double dq = cx.sum1(delta * cx.Q[0]), rq = cx.sum1(r * cx.Q[0]);
+            if (slot < 1024 && lead) {
+              double *q = dbg_buf + (size_t)slot * 8;
+              q[0] = r_r; q[1] = d_Hd; q[2] = alpha; q[3] = model_value; q[4] = v[4]; q[5] = Hd_Hd;
+              q[6] = dq; q[7] = rq;
+            }
+          }
+#endif
           const double e_Pe_new = fma(alpha, fma(alpha, d_Pd, e_Pd2), e_Pe);           // :506
           // <r',r'>/<r,r> = 1 + (2 <r,Hdelta> + alpha |Hdelta|^2) / <delta,Hdelta>   (alpha/<r,r> = rho)
-          const double beta_p = fma(fma(alpha, Hd_Hd, v[4] + v[4]), rho, 1.0);         // :592 predicted
+          const double beta_p = fma(fma(alpha, Hd_Hd, -(v[4] + v[4])), rho, 1.0);      // :592 predicted
           double new_r_r = beta_p * r_r;                                               // :564 predicted
           const double new_eta = fma(alpha, delta, eta);      // :538
           const double new_Heta = fma(alpha, Hdelta, Heta);   // :542
           const double new_r = fma(alpha, Hdelta, r);         // :561
+          const double new_w = fma(-alpha, Hdelta, w);
           const bool plain = model_value < model_prev && d_Hd > 0.0 && e_Pe_new < Delta2 &&
                              beta_p >= 1e-3 && !(j >= p.mininner && new_r_r <= target2);
           double beta = beta_p;
@@ -177,7 +200,8 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
           eta = new_eta;                                    // :556-558
           Heta = new_Heta;
           r = new_r;                                        // :561
-          delta = fma(beta, delta, -r);                     // :593
+          w = new_w;
+          delta = fma(beta, delta, w);                      // :593
           e_Pd2 = beta * fma(alpha + alpha, d_Pd, e_Pd2);   // :596 (carried as 2 <eta, delta>)
           d_Pd = fma(beta * beta, d_Pd, new_r_r);           // :597
         }
