@@ -470,7 +470,21 @@ struct WaveCtx {
       // c = d - target where the term is active, else 0: -clamp(target - d, lo, hi).  A hinge is
       // active iff its clamped residual is non-zero (psi_L - d > 0 / d - psi_U > 0), an equality
       // always: lo * hi = -inf only for EQ (0 * inf = NaN and 0 * 0 = 0 compare false).
-      const double cl = fmin(fmax(rc.tg - d, (double)rc.lo), (double)rc.hi);
+      const double cl_own = fmin(fmax(rc.tg - d, (double)rc.lo), (double)rc.hi);
+      // One residual per TERM: d above is summed in this lane's rotated component order, so the K
+      // lanes of a node (and the two ends of an edge) would carry residuals that differ in the
+      // last bit.  That makes the round-off of the gradient a vector that is no longer of the form
+      // sum_e s_e (e_i - e_j) y_e^T -- the form is horizontal and translation-free exactly, and
+      // the reference's G[i] += t, G[j] -= t has it -- and a vertical component of 1e-16 in the
+      // start residual of tCG is enough to delay it (measured on UR10: +12 % Hessian products).
+      // Every lane therefore uses the value of its node's component-0 lane, which sums in natural
+      // order at both ends of the edge.
+      double cl;
+      if constexpr (K == 3)
+        cl = bit_select(comp >= 1, bit_select(comp >= 2, wave_shr<2>(cl_own), wave_shr<1>(cl_own)),
+                        cl_own);
+      else
+        cl = bit_select(comp >= 1, wave_shr<1>(cl_own), cl_own);
       const bool act = (rc.lo * rc.hi < 0.0f) || (cl != 0.0);
       const double c = -cl;
       const double a2 = act ? 2.0 * y[0] : 0.0;          // 2 a y_c, a in {0,1}
