@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GIK_LIB_PATH") or os.path.join(_HERE, "lib", "libgraphik_amd.so")
 
 TERM_EQ, TERM_LOWER, TERM_UPPER = 1, 2, 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class TemplateDesc(C.Structure):

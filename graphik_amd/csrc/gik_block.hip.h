@@ -27,6 +27,9 @@ template <int K>
 struct BlockCtx {
   static constexpr int NC = (K == 3) ? 3 : 1;
   static constexpr int RS = 4;  // LDS row stride (doubles): 32-byte rows
+  static constexpr bool HAS_CK = false;   // no tCG checkpoint (rtr_solve_one "Retrace") on this path
+  __device__ inline void ck_put(int, double) {}
+  __device__ inline double ck_get(int) const { return 0.0; }
 
   int tid, lane, wave, node, part, N, SL, SLE;  // slots [0, SLE) hold equality terms or padding only
   bool active;       // owns an unknown: node < N && part < K

@@ -24,6 +24,7 @@ namespace gik {
 struct RtrOut {
   double f, gradnorm;
   int iterations, inner_total, stop, n_accept;
+  int inner_executed;   // Hessian products actually evaluated (<= the reference's count, see "Retrace")
 };
 
 // ||g||_F together with <g, pk2_m> in one reduction
@@ -46,6 +47,12 @@ __device__ inline double grad_norm_and_rho(Ctx &cx, double g, double (&rho0)[Ctx
   return sqrt(v[0]);
 }
 
+// tau of trust_region.py:514 with <eta, delta> carried doubled
+__device__ inline double boundary_tau(double e_Pd2, double d_Pd, double Delta2, double e_Pe) {
+  const double e_Pd = 0.5 * e_Pd2;
+  return (sqrt(fma(e_Pd, e_Pd, d_Pd * (Delta2 - e_Pe))) - e_Pd) / d_Pd;   // no contraction left open
+}
+
 // THETA_ONE: compiled for the reference default theta = 1 (trust_region.py:92), where
 // norm_r0 ** theta needs no pow().  The generic build evaluates pow() when theta != 1; inlined, its
 // polynomial constants are hoisted to the per-problem setup and spilled to scratch by every problem
@@ -62,7 +69,25 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
     // ||grad|| (:161) and rho0_m = <grad, pk2_m> (start values of the tCG recurrences)
     double rho0[Ctx::NC];
     double norm_grad = grad_norm_and_rho(cx, g, rho0);
-    int kiter = 0, inner_total = 0, n_accept = 0, stop = 1;
+    int kiter = 0, inner_total = 0, inner_exec = 0, n_accept = 0, stop = 1;
+    // ---- Retrace (k = 3 wave path) --------------------------------------------------------
+    // A rejected step leaves x, g and the Hessian unchanged and divides the radius by 4
+    // (:336-338, :382), so the reference's next tCG solve repeats the previous one operation for
+    // operation until |eta| passes the smaller radius -- 11 % of all Hessian products on random
+    // LWA4D goals.  Every tCG solve therefore leaves a checkpoint where it first meets its own
+    // radius / 4 (vectors in LDS, scalars in registers); after a rejection the boundary step is
+    // formed from the checkpoint with the same arithmetic the rerun would end in, bit for bit
+    // (tests: results identical with GIK_DBG=16, which disables this).  A solve that ended inside
+    // the smaller radius without meeting it (model / target / maxinner exits) is its own rerun.
+    // inner_total keeps counting what the reference would have executed.
+    constexpr bool RETRACE = (K == 3) && Ctx::HAS_CK;
+    const bool retrace_on = RETRACE && !(dbg & 16);
+    bool prev_rejected = false, ck_set = false, ck_neg = false;
+    int ck_j = 0;
+    double ck_T = 0.0, ck_e_Pe = 0.0, ck_e_Pd2 = 0.0, ck_d_Pd = 0.0;
+    double last_Delta2 = 0.0, last_e_Pe = 0.0;
+    double eta = 0.0, Heta = 0.0;
+    int stop_tCG = TCG_MAX_INNER_ITER, j = 0;
     const bool prof = (dbg & 8) && b == 0 && dbg_buf;   // cycle counters (developer aid)
     long long prof_tcg = 0;
     const long long prof_t0 = prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -71,11 +96,36 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
 
     while (!bad) {
       // -------------- _truncated_conjugate_gradient (trust_region.py:436-599) -------------
-      double eta = 0.0, Heta = 0.0;              // :444-445
-      int stop_tCG = TCG_MAX_INNER_ITER;         // :491
-      int j = 0;
+      const double Delta2 = Delta * Delta;
+      bool reuse = false;
+      if constexpr (RETRACE) {
+        if (retrace_on && prev_rejected) {
+          if (Delta2 == last_Delta2) {
+            reuse = true;                                  // same radius: the identical solve
+          } else if (ck_set && Delta2 == ck_T) {           // the rerun stops at the checkpoint
+            const double tau = boundary_tau(ck_e_Pd2, ck_d_Pd, Delta2, ck_e_Pe);       // :514
+            eta = fma(tau, cx.ck_get(2), cx.ck_get(0));                                // :516
+            Heta = fma(tau, cx.ck_get(3), cx.ck_get(1));                               // :521
+            stop_tCG = ck_neg ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;
+            j = ck_j;
+            ck_set = false;
+            reuse = true;
+          } else if (stop_tCG != TCG_NEGATIVE_CURVATURE && stop_tCG != TCG_EXCEEDED_TR &&
+                     last_e_Pe < Delta2) {
+            reuse = true;                                  // never met the smaller radius either
+          }
+        }
+      }
+      last_Delta2 = Delta2;
       const long long prof_t1 = prof ? (long long)__builtin_readcyclecounter() : 0;
-      if constexpr (K == 3) {
+      int executed = 0;
+      if (reuse) {
+        // eta, Heta, j, stop_tCG are the rerun's
+      } else if constexpr (K == 3) {
+        double eta_l = 0.0, Heta_l = 0.0;          // :444-445 (loop-local: the outer copies must
+                                                   // not constrain the loop's register allocation)
+        stop_tCG = TCG_MAX_INNER_ITER;             // :491
+        int extra = 0;
         // One reduction per inner iteration.  The projector P = I - Q Q^T is orthogonal, so for
         // HORIZONTAL delta and w (= -P r, see below), with H = ehess(delta), u = Q^T H,
         // Hdelta = H - Q u:
@@ -101,7 +151,10 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         const double nr0_theta = (THETA_ONE || p.theta == 1.0) ? norm_grad : pow(norm_grad, p.theta);
         const double target = norm_grad * fmin(nr0_theta, p.kappa);  // rhs of :572
         const double target2 = target * target;
-        const double Delta2 = Delta * Delta;
+        // radius the plain path tests against: Delta2 / 16 until the checkpoint is taken
+        const double Tq = 0.0625 * Delta2;
+        double T_cur = RETRACE ? Tq : Delta2;
+        ck_set = !RETRACE;
         // w = -(horizontal part of r).  The reference never projects the gradient
         // (fixed_rank_psd_sym.py:123-124), so r carries the vertical round-off of egrad for the
         // whole solve (every Hdelta is horizontal) and delta = -r + beta delta accumulates it.  Its
@@ -124,7 +177,7 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         for (j = 0; j < p.maxinner; ++j) {         // :495
           const double H = cx.ehess(delta);        // :497
           double v[8] = {cx.Q[0] * H, cx.Q[1] * H, cx.Q[2] * H,      delta * H,
-                         w * H,       H * H,       eta * fma(0.5, Heta, g), r * r};
+                         w * H,       H * H,       eta_l * fma(0.5, Heta_l, g), r * r};
           cx.template sum_n<8>(v);
           const double Hdelta = fma(-cx.Q[2], v[2], fma(-cx.Q[1], v[1], fma(-cx.Q[0], v[0], H)));
           const double d_Hd = v[3];                // :500
@@ -148,30 +201,50 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
           // <r',r'>/<r,r> = 1 + (2 <r,Hdelta> + alpha |Hdelta|^2) / <delta,Hdelta>   (alpha/<r,r> = rho)
           const double beta_p = fma(fma(alpha, Hd_Hd, -(v[4] + v[4])), rho, 1.0);      // :592 predicted
           double new_r_r = beta_p * r_r;                                               // :564 predicted
-          const double new_eta = fma(alpha, delta, eta);      // :538
-          const double new_Heta = fma(alpha, Hdelta, Heta);   // :542
+          const double new_eta = fma(alpha, delta, eta_l);      // :538
+          const double new_Heta = fma(alpha, Hdelta, Heta_l);   // :542
           const double new_r = fma(alpha, Hdelta, r);         // :561
           const double new_w = fma(-alpha, Hdelta, w);
-          const bool plain = model_value < model_prev && d_Hd > 0.0 && e_Pe_new < Delta2 &&
-                             beta_p >= 1e-3 && !(j >= p.mininner && new_r_r <= target2);
+          // & rather than &&, and the cold block marked unlikely: five compares and scalar ands
+          // with the hot path laid out as a fall-through chain.  Short-circuit evaluation put a
+          // taken branch into every iteration, the default block placement two more (measured
+          // 1072 -> 1048 -> 1004 cycles per iteration)
+          const bool plain = (model_value < model_prev) & (d_Hd > 0.0) & (e_Pe_new < T_cur) &
+                             (beta_p >= 1e-3) & !((j >= p.mininner) & (new_r_r <= target2));
           double beta = beta_p;
-          if (UNI(!plain)) {   // any exit, a NaN, or the accuracy guard
+          if (__builtin_expect(UNI(!plain), 0)) {   // any exit, a NaN, or the accuracy guard
             if (!(d_Hd == d_Hd) || !(new_r_r == new_r_r) || !(model_value == model_value)) {
               bad = true;
               break;
             }
             if (model_value >= model_prev) {                    // :552 of step j-1
-              eta = eta_prev;
-              Heta = Heta_prev;
+              eta_l = eta_prev;
+              Heta_l = Heta_prev;
               stop_tCG = TCG_MODEL_INCREASED;
+              extra = 1;
               j = j - 1;
               break;
             }
+            if constexpr (RETRACE) {
+              if (!ck_set && (d_Hd <= 0.0 || e_Pe_new >= Tq)) {   // first meeting with radius / 4
+                cx.ck_put(0, eta_l);
+                cx.ck_put(1, Heta_l);
+                cx.ck_put(2, delta);
+                cx.ck_put(3, Hdelta);
+                ck_e_Pe = e_Pe;
+                ck_e_Pd2 = e_Pd2;
+                ck_d_Pd = d_Pd;
+                ck_j = j;
+                ck_neg = d_Hd <= 0.0;
+                ck_T = Tq;
+                ck_set = true;
+                T_cur = Delta2;
+              }
+            }
             if (d_Hd <= 0.0 || e_Pe_new >= Delta2) {           // :509
-              const double e_Pd = 0.5 * e_Pd2;
-              const double tau = (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta2 - e_Pe))) / d_Pd;  // :514
-              eta = eta + tau * delta;                          // :516
-              Heta = Heta + tau * Hdelta;                       // :521
+              const double tau = boundary_tau(e_Pd2, d_Pd, Delta2, e_Pe);           // :514
+              eta_l = fma(tau, delta, eta_l);                       // :516
+              Heta_l = fma(tau, Hdelta, Heta_l);                    // :521
               stop_tCG = (d_Hd <= 0.0) ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;  // :531-534
               break;
             }
@@ -180,13 +253,14 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
               beta = new_r_r / r_r;
             }
             if (j >= p.mininner && new_r_r <= target2) {        // :572
+              e_Pe = e_Pe_new;   // this step passed the radius test (what a rerun has to pass again)
               // the reference tests the model of this step first (:552)
               const double model_new = cx.sum1(new_eta * fma(0.5, new_Heta, g));
               if (model_new >= model_value) {
                 stop_tCG = TCG_MODEL_INCREASED;
               } else {
-                eta = new_eta;
-                Heta = new_Heta;
+                eta_l = new_eta;
+                Heta_l = new_Heta;
                 stop_tCG = (p.kappa < nr0_theta) ? TCG_REACHED_TARGET_LINEAR
                                                  : TCG_REACHED_TARGET_SUPERLINEAR;
               }
@@ -194,11 +268,11 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
             }
           }
           e_Pe = e_Pe_new;                                  // :537
-          eta_prev = eta;
-          Heta_prev = Heta;
+          eta_prev = eta_l;
+          Heta_prev = Heta_l;
           model_prev = model_value;
-          eta = new_eta;                                    // :556-558
-          Heta = new_Heta;
+          eta_l = new_eta;                                    // :556-558
+          Heta_l = new_Heta;
           r = new_r;                                        // :561
           w = new_w;
           delta = fma(beta, delta, w);                      // :593
@@ -207,14 +281,21 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         }
         if (!bad && j >= p.maxinner) {
           // inner iterations exhausted with the model test of the last step still pending
-          const double model_last = cx.sum1(eta * fma(0.5, Heta, g));
+          const double model_last = cx.sum1(eta_l * fma(0.5, Heta_l, g));
           if (model_last >= model_prev) {
-            eta = eta_prev;
-            Heta = Heta_prev;
+            eta_l = eta_prev;
+            Heta_l = Heta_prev;
             stop_tCG = TCG_MODEL_INCREASED;
           }
         }
+        last_e_Pe = e_Pe;
+        eta = eta_l;
+        Heta = Heta_l;
+        executed = (j >= p.maxinner ? p.maxinner : j + 1) + extra;
       } else {
+        eta = 0.0;                                 // :444-445
+        Heta = 0.0;
+        stop_tCG = TCG_MAX_INNER_ITER;             // :491
         double r = g;                              // :448
         double e_Pe = 0.0;
         double r_r = cx.sum1(r * r);              // :455
@@ -286,11 +367,13 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
           e_Pd = beta * (e_Pd + alpha * d_Pd);              // :596
           d_Pd = z_r + beta * beta * d_Pd;                  // :597
         }
+        executed = j >= p.maxinner ? p.maxinner : j + 1;
       }
       if (prof) prof_tcg += (long long)__builtin_readcyclecounter() - prof_t1;
       if (bad) break;
       if (j >= p.maxinner) j = p.maxinner - 1;  // Python leaves j at the last index
       inner_total += j + 1;
+      inner_exec += executed;
 
       // -------------- outer iteration (trust_region.py:248-422) ---------------------------
       if (has_trace && kiter < trace.cap && lead) {
@@ -319,8 +402,10 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         Delta = fmin(2.0 * Delta, Delta_bar);            // :357-361
       }
       int accept = 0;
+      prev_rejected = true;
       if (UNI(model_decreased && rho > p.rho_prime)) {   // :382
         accept = 1;
+        prev_rejected = false;
         ++n_accept;
         x = x_prop;                                      // :385
         fx = fx_prop;                                    // :386
@@ -345,12 +430,14 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
       dbg_buf[0] = (double)prof_tcg;
       dbg_buf[1] = (double)inner_total;
       dbg_buf[2] = (double)((long long)__builtin_readcyclecounter() - prof_t0);
+      dbg_buf[3] = (double)inner_exec;
     }
 
     out.f = fx;
     out.gradnorm = norm_grad;
     out.iterations = kiter;
     out.inner_total = inner_total;
+    out.inner_executed = inner_exec;
     out.stop = stop;
     out.n_accept = n_accept;
 }

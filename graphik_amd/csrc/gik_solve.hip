@@ -37,7 +37,8 @@ struct SolveArgs {
   int N, T, B;
   int dbg;  // debug flags (env GIK_DBG): 1 = one block per problem, 2 = skip the TR loop,
             // 4 = dump (r_r, d_Hd, alpha, model) of every inner iteration of problem 0 to dbg_buf,
-            // 8 = cycle counters of problem 0: dbg_buf = {cycles in tCG loops, tCG iterations, all cycles}
+            // 8 = cycle counters of problem 0: dbg_buf = {cycles in tCG loops, tCG iterations, all cycles},
+            // 16 = rerun tCG after every rejected step instead of resuming from the checkpoint
   double *dbg_buf;
   Params p;
 };
@@ -102,6 +103,8 @@ __global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
       s.inner_total = inner_total;
       s.stop = stop;
       s.n_accept = n_accept;
+      s.inner_executed = ro.inner_executed;
+      s.reserved = 0;
       a.stats[b] = s;
     }
   }
@@ -212,6 +215,8 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
       s.inner_total = ro.inner_total;
       s.stop = ro.stop;
       s.n_accept = ro.n_accept;
+      s.inner_executed = ro.inner_executed;
+      s.reserved = 0;
       a.stats[b] = s;
     }
   }

@@ -322,13 +322,18 @@ struct WaveCtx {
     float lo, hi;
   };
   // LDS carve: K tiles | targets[T] | slot meta (MAXDEG*64 u32) | slot records (MAXDEG*64 x 16 B)
+  //            | tCG checkpoint (4 x 64 doubles, k = 3: see "Retrace" in rtr_solve_one)
+  static constexpr bool HAS_CK = (K == 3);
   __host__ __device__ static constexpr size_t lds_bytes(int T) {
     return sizeof(double) * ((size_t)K * TILE + (size_t)((T + 1) & ~1)) +
-           sizeof(uint32_t) * (size_t)MAXDEG * WAVE + sizeof(SlotRec) * (size_t)MAXDEG * WAVE;
+           sizeof(uint32_t) * (size_t)MAXDEG * WAVE + sizeof(SlotRec) * (size_t)MAXDEG * WAVE +
+           (HAS_CK ? sizeof(double) * 4 * WAVE : 0);
   }
   __device__ static inline SlotRec *rec_base(uint32_t *meta) {
     return reinterpret_cast<SlotRec *>(meta + MAXDEG * WAVE);
   }
+  __device__ inline void ck_put(int i, double v) { sh_ck[i * WAVE + lane] = v; }
+  __device__ inline double ck_get(int i) const { return sh_ck[i * WAVE + lane]; }
 
   int lane, node, comp;
   bool active;
@@ -345,6 +350,7 @@ struct WaveCtx {
   const double *sh_tgt;    // [T] per-problem residual targets
   const uint32_t *sh_meta; // [MAXDEG][64]
   SlotRec *sh_rec;         // [MAXDEG][64]
+  double *sh_ck;           // [4][64] tCG checkpoint (own lane only: no barrier needed)
   int waddr[K];            // where this lane's value goes in tile 0..K-1 (double index)
   int own_off;             // this lane's node row in its own tile (double index)
   int nat_off;             // this lane's node row in tile 0 (natural component order)
@@ -403,6 +409,7 @@ struct WaveCtx {
                               uint32_t *meta) {
     lane = lane_;
     sh_rec = rec_base(meta);
+    sh_ck = reinterpret_cast<double *>(sh_rec + MAXDEG * WAVE);
     active = lane < N * K;
     node = active ? lane / K : (TILE_ROWS - 1);
     comp = active ? lane - node * K : 0;

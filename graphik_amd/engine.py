@@ -273,12 +273,12 @@ class Template:
         return {"x": out["Y"].reshape(B, self.N, self.k), "q": out["q"], "pos_err": out["pos_err"],
                 "rot_err": out["rot_err"], "f": out["stats"][:, 0], "gradnorm": out["stats"][:, 1],
                 "iterations": ints[:, 4], "inner_total": ints[:, 5], "stop": ints[:, 6],
-                "n_accept": ints[:, 7]}
+                "n_accept": ints[:, 7], "inner_executed": ints[:, 8]}
 
     def alloc_ik_buffers(self, B):
         f64 = dict(dtype=torch.float64, device=self.device)
         return {"targets": torch.empty(B, self.T, **f64), "Y": torch.empty(B, self.N * self.k, **f64),
-                "stats": torch.zeros(B, 4, **f64), "q": torch.empty(B, self.n_joints, **f64),
+                "stats": torch.zeros(B, 5, **f64), "q": torch.empty(B, self.n_joints, **f64),
                 "pos_err": torch.empty(B, **f64), "rot_err": torch.empty(B, **f64)}
 
     # -- trust-region solve -------------------------------------------------------------------
@@ -288,7 +288,7 @@ class Template:
         Y, B = self._vec(Y_init)
         t = self._tg(targets, B)
         out = torch.empty_like(Y)
-        stats = torch.zeros(B, 4, dtype=torch.float64, device=self.device)  # 32 B / problem
+        stats = torch.zeros(B, 5, dtype=torch.float64, device=self.device)  # gik_stats: 40 B / problem
         tr = None
         keep = {}
         if trace_cap > 0:
@@ -305,10 +305,10 @@ class Template:
                                                 out.data_ptr(), stats.data_ptr(),
                                                 C.byref(tr) if tr is not None else None,
                                                 self._stream()))
-        ints = stats.view(torch.int32)  # [B, 8]
+        ints = stats.view(torch.int32)  # [B, 10]
         res = {"x": out.reshape(B, self.N, self.k), "f": stats[:, 0], "gradnorm": stats[:, 1],
                "iterations": ints[:, 4], "inner_total": ints[:, 5], "stop": ints[:, 6],
-               "n_accept": ints[:, 7]}
+               "n_accept": ints[:, 7], "inner_executed": ints[:, 8]}
         if tr is not None:
             res["trace"] = keep
         return res

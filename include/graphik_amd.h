@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GIK_ABI_VERSION 1
+#define GIK_ABI_VERSION 2
 
 /* Residual-term kinds: one "term" per (index pair, kind) exactly as the loops of
  * costs.py:80-207 visit them: equality (omega != 0), lower hinge (psi_L != 0), upper hinge
@@ -80,7 +80,12 @@ typedef struct {
                           "model increased" exit costs one product more than it reports  */
   int32_t stop;        /* 0: gradnorm < mingradnorm, 1: maxiter, 2: NaN encountered       */
   int32_t n_accept;    /* accepted steps                                                  */
-} gik_stats;
+  int32_t inner_executed; /* Hessian products actually evaluated: after a rejected step the
+                          reference's next tCG solve repeats the previous one up to the smaller
+                          radius, and the engine resumes from a checkpoint instead (same result,
+                          bit for bit); inner_total counts what the reference would have run   */
+  int32_t reserved;
+} gik_stats;            /* 40 bytes                                                         */
 
 /* Optional per-outer-iteration trace (device arrays of B x cap; pass NULL to disable). */
 typedef struct {

@@ -295,6 +295,38 @@ def test_full_size_batch_properties(torch_cuda):
     assert 0.6 < np.median(its[:48]) / np.median(o["iterations"]) < 1.6
 
 
+@pytest.mark.parametrize("name", ["lwa4d", "kuka"])
+def test_checkpoint_resume_is_bit_identical(torch_cuda, monkeypatch, name):
+    """After a rejected step the reference's next tCG solve repeats the previous one up to the
+    smaller radius; the engine resumes from a checkpoint instead.  Same arithmetic, so the results
+    (points, costs, every counter the reference would report, the per-iteration trace) must equal
+    those of actually rerunning tCG (GIK_DBG=16), bit for bit; only the executed work differs."""
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    robot, graph = make_graph(name)
+    prob = BatchProblem(graph, use_limits=True)
+    rng = np.random.RandomState(21)
+    Tg = robot.fk_batch(-np.pi + 2 * np.pi * rng.rand(384, robot.n))
+    targets, Y0 = prob.prepare(Tg)
+
+    def run():
+        r = prob.template.solve(Y0, targets, trace_cap=96)
+        out = {k: r[k].cpu().numpy() for k in ("x", "f", "gradnorm", "iterations", "inner_total",
+                                              "stop", "n_accept", "inner_executed")}
+        out.update({"t_" + k: v.cpu().numpy() for k, v in r["trace"].items()})
+        return out
+
+    a = run()
+    monkeypatch.setenv("GIK_DBG", "16")
+    b = run()
+    monkeypatch.delenv("GIK_DBG")
+    for k in a:
+        if k != "inner_executed":
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert np.all(b["inner_executed"] >= b["inner_total"])       # rerun: every counted product runs
+    assert np.all(a["inner_executed"] <= b["inner_executed"])
+    assert a["inner_executed"].sum() < 0.95 * b["inner_executed"].sum()   # measured: -11 ... -14 %
+
+
 def test_results_independent_of_persistent_grid(torch_cuda, monkeypatch):
     """The solve kernel is persistent (waves claim problems from a queue); the number of resident
     waves is a scheduling choice (one or two per SIMD, gik_solve_batch) and must not change a

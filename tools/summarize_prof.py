@@ -66,7 +66,7 @@ print(open(os.path.join(out, f"{tag}_kernel_stats.csv")).read())
 s = summary[solve]
 if "SQ_INSTS_VALU" in s:
     b = json.loads(open(os.path.join(out, f"{tag}_bench_n1.json")).read())
-    hv = b["hv_products"]["total_per_gpu"]
+    hv = b["hv_products"].get("executed_per_gpu", b["hv_products"]["total_per_gpu"])
     print("per tCG iteration: VALU %.1f  LDS %.1f  MFMA %.2f  SALU %.1f  wave cycles %.0f  (hv %d)" % (
         s["SQ_INSTS_VALU"] / hv, s["SQ_INSTS_LDS"] / hv, s.get("SQ_INSTS_MFMA", 0) / hv,
         s["SQ_INSTS_SALU"] / hv, s["SQ_WAVE_CYCLES"] / hv, hv))
