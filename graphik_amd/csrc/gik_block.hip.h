@@ -27,9 +27,10 @@ template <int K>
 struct BlockCtx {
   static constexpr int NC = (K == 3) ? 3 : 1;
   static constexpr int RS = 4;  // LDS row stride (doubles): 32-byte rows
-  static constexpr bool HAS_CK = false;   // no tCG checkpoint (rtr_solve_one "Retrace") on this path
-  __device__ inline void ck_put(int, double) {}
-  __device__ inline double ck_get(int) const { return 0.0; }
+  static constexpr bool HAS_CK = (K == 3);   // tCG checkpoint (rtr_solve_one "Retrace"): [4][512] doubles
+  double *sh_ck;
+  __device__ inline void ck_put(int i, double v) { sh_ck[i * BLOCK_NT + tid] = v; }   // own thread only
+  __device__ inline double ck_get(int i) const { return sh_ck[i * BLOCK_NT + tid]; }
 
   int tid, lane, wave, node, part, N, SL, SLE;  // slots [0, SLE) hold equality terms or padding only
   bool active;       // owns an unknown: node < N && part < K
@@ -47,7 +48,7 @@ struct BlockCtx {
 
   __host__ __device__ static constexpr size_t lds_bytes(int T, int SL) {
     return sizeof(double) * ((size_t)3 * BLOCK_MAXN * RS + (size_t)((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES) +
-           sizeof(uint32_t) * (size_t)SL * BLOCK_NT;
+           sizeof(uint32_t) * (size_t)SL * BLOCK_NT + (HAS_CK ? sizeof(double) * 4 * BLOCK_NT : 0);
   }
 
   __device__ inline bool lead() const { return tid == 0; }
@@ -69,6 +70,7 @@ struct BlockCtx {
     sh_tgt = tg;
     sh_red = tg + ((T + 1) & ~1);
     sh_slots = slots_lds;
+    sh_ck = reinterpret_cast<double *>(const_cast<uint32_t *>(slots_lds) + (size_t)SL_ * BLOCK_NT);
     red_buf = 0;
   }
 

@@ -295,21 +295,25 @@ def test_full_size_batch_properties(torch_cuda):
     assert 0.6 < np.median(its[:48]) / np.median(o["iterations"]) < 1.6
 
 
-@pytest.mark.parametrize("name", ["lwa4d", "kuka"])
+@pytest.mark.parametrize("name", ["lwa4d", "kuka", "lwa4d_block"])
 def test_checkpoint_resume_is_bit_identical(torch_cuda, monkeypatch, name):
     """After a rejected step the reference's next tCG solve repeats the previous one up to the
     smaller radius; the engine resumes from a checkpoint instead.  Same arithmetic, so the results
     (points, costs, every counter the reference would report, the per-iteration trace) must equal
     those of actually rerunning tCG (GIK_DBG=16), bit for bit; only the executed work differs."""
     from graphik_amd.solvers.riemannian_solver import BatchProblem
-    robot, graph = make_graph(name)
+    from graphik_amd.engine import Template
+    block = name.endswith("_block")          # the workgroup-per-problem kernel keeps its checkpoint too
+    robot, graph = make_graph(name.split("_")[0])
     prob = BatchProblem(graph, use_limits=True)
     rng = np.random.RandomState(21)
-    Tg = robot.fk_batch(-np.pi + 2 * np.pi * rng.rand(384, robot.n))
+    Tg = robot.fk_batch(-np.pi + 2 * np.pi * rng.rand(96 if block else 384, robot.n))
     targets, Y0 = prob.prepare(Tg)
+    tpl = prob.template if not block else Template.from_matrices(
+        prob.omega, prob.psi_L, prob.psi_U, k=3, use_limits=True, params={"force_block_path": 1})
 
     def run():
-        r = prob.template.solve(Y0, targets, trace_cap=96)
+        r = tpl.solve(Y0, targets, trace_cap=96)
         out = {k: r[k].cpu().numpy() for k in ("x", "f", "gradnorm", "iterations", "inner_total",
                                               "stop", "n_accept", "inner_executed")}
         out.update({"t_" + k: v.cpu().numpy() for k, v in r["trace"].items()})
