@@ -678,6 +678,11 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   }
   t->n_cu = prop.multiProcessorCount;
   t->waves_per_cu = std::max(1, std::min(occ, 32));
+  if (const char *e = getenv("GIK_DBG"))
+    if (atoi(e) & 32)
+      fprintf(stderr, "gik_template_create: N=%d k=%d T=%d %s maxdeg=%d lds=%zu B occupancy=%d per CU, %d CUs\n",
+              t->N, t->K, t->T, is_block ? "block" : "wave", is_block ? 0 : t->variant->maxdeg,
+              t->smem_bytes, occ, t->n_cu);
   *out = t;
   return 0;
 }
@@ -888,8 +893,8 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   // Persistent waves per CU.  A wavefront that shares its SIMD runs ~20 % slower, and the batch
   // time of a few thousand goals is the run time of its slowest problem, so small batches get one
   // wave per SIMD; with more than ~12 problems per SIMD the throughput of two waves per SIMD wins
-  // (measured on LWA4D, kernel ms at 1 / 2 waves per SIMD: B=4096 141 / 152, B=8192 174 / 188,
-  // B=16384 231 / 209).
+  // (measured on LWA4D, kernel ms at 1 / 2 waves per SIMD: B=4096 120 / 130, B=8192 151 / 173,
+  // B=16384 196 / 172-185).
   int wpc = t->waves_per_cu;
   // (planar problems are short and uniform: full occupancy is 7 % faster there)
   if (!t->is_block && t->K == 3 && wpc > 4 && (long long)B <= 12LL * 4 * t->n_cu) wpc = 4;
