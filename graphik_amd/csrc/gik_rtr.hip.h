@@ -166,18 +166,30 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         // identities above hold to rounding; r itself, <r, r>, alpha and beta stay the reference's.
         double w = fma(rho0[2], cx.Q[2], fma(rho0[1], cx.Q[1], fma(rho0[0], cx.Q[0], -g)));
         double delta = w;                          // :469 (horizontal part)
-        double e_Pe = 0.0, e_Pd2 = 0.0, d_Pd = r0_r0;  // :464-471 (precon = identity)
+        double e_Pd2 = 0.0, d_Pd = r0_r0;          // :464-471 (precon = identity); <eta,eta> below
         double model_prev = __builtin_inf();       // model value before the last step (:485: 0)
-        double eta_prev = 0.0, Heta_prev = 0.0;
+        // eta, Heta and <eta, eta> live in two register sets, A and B.  A step reads the current
+        // set and writes the new values into the other one -- which until then holds the PREVIOUS
+        // eta / Heta, exactly what the deferred model test rolls back to -- and the loop body is two
+        // steps with the roles swapped.  Written with one set and `prev = cur; cur = new`, every
+        // iteration pays seven v_mov_b64 register rotations (~10 cycles each for a lone wavefront;
+        // `#pragma unroll` is ignored on this loop).
+        double ea = 0.0, ha = 0.0, pa = 0.0;       // :444-445, :464
+        double eb = 0.0, hb = 0.0, pb = 0.0;
+        double e_Pe_end = 0.0;                     // <eta, eta> of the last step that passed the radius test
         // Drain every outstanding memory operation before the loop: a pending FLAT access (the
         // trace stores of the outer iteration) may return out of order with LDS, and as long as
         // the compiler has to assume one at the loop header it turns the first staged
         // s_waitcnt lgkmcnt(n) of every Hessian product into lgkmcnt(0).
         __builtin_amdgcn_s_waitcnt(0);
-        for (j = 0; j < p.maxinner; ++j) {         // :495
+        // One tCG iteration (:495-597).  (ec, hc, pc): current eta, Heta, <eta,eta>; (en, hn): the
+        // previous eta, Heta on entry, the new ones on a plain return; pn: the new <eta,eta>.
+        // Returns true when tCG ends (result in eta_l / Heta_l, or `bad`).
+        auto step = [&](const double ec, const double hc, const double pc, double &en, double &hn,
+                        double &pn) __attribute__((always_inline)) -> bool {
           const double H = cx.ehess(delta);        // :497
           double v[8] = {cx.Q[0] * H, cx.Q[1] * H, cx.Q[2] * H,      delta * H,
-                         w * H,       H * H,       eta_l * fma(0.5, Heta_l, g), r * r};
+                         w * H,       H * H,       ec * fma(0.5, hc, g), r * r};
           cx.template sum_n<8>(v);
           const double Hdelta = fma(-cx.Q[2], v[2], fma(-cx.Q[1], v[1], fma(-cx.Q[0], v[0], H)));
           const double d_Hd = v[3];                // :500
@@ -197,41 +209,41 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
             }
           }
 #endif
-          const double e_Pe_new = fma(alpha, fma(alpha, d_Pd, e_Pd2), e_Pe);           // :506
+          const double e_Pe_new = fma(alpha, fma(alpha, d_Pd, e_Pd2), pc);             // :506
           // <r',r'>/<r,r> = 1 + (2 <r,Hdelta> + alpha |Hdelta|^2) / <delta,Hdelta>   (alpha/<r,r> = rho)
           const double beta_p = fma(fma(alpha, Hd_Hd, -(v[4] + v[4])), rho, 1.0);      // :592 predicted
           double new_r_r = beta_p * r_r;                                               // :564 predicted
-          const double new_eta = fma(alpha, delta, eta_l);      // :538
-          const double new_Heta = fma(alpha, Hdelta, Heta_l);   // :542
-          const double new_r = fma(alpha, Hdelta, r);         // :561
-          const double new_w = fma(-alpha, Hdelta, w);
           // & rather than &&, and the cold block marked unlikely: five compares and scalar ands
           // with the hot path laid out as a fall-through chain.  Short-circuit evaluation put a
           // taken branch into every iteration, the default block placement two more (measured
           // 1072 -> 1048 -> 1004 cycles per iteration)
+          // (the last permitted iteration, :495, is routed through the cold block as well, so
+          // that the loop has a single exit edge)
           const bool plain = (model_value < model_prev) & (d_Hd > 0.0) & (e_Pe_new < T_cur) &
-                             (beta_p >= 1e-3) & !((j >= p.mininner) & (new_r_r <= target2));
+                             (beta_p >= 1e-3) & !((j >= p.mininner) & (new_r_r <= target2)) &
+                             (j + 1 < p.maxinner);
           double beta = beta_p;
           if (__builtin_expect(UNI(!plain), 0)) {   // any exit, a NaN, or the accuracy guard
             if (!(d_Hd == d_Hd) || !(new_r_r == new_r_r) || !(model_value == model_value)) {
               bad = true;
-              break;
+              return true;
             }
             if (model_value >= model_prev) {                    // :552 of step j-1
-              eta_l = eta_prev;
-              Heta_l = Heta_prev;
+              eta_l = en;
+              Heta_l = hn;
+              e_Pe_end = pc;
               stop_tCG = TCG_MODEL_INCREASED;
               extra = 1;
               j = j - 1;
-              break;
+              return true;
             }
             if constexpr (RETRACE) {
               if (!ck_set && (d_Hd <= 0.0 || e_Pe_new >= Tq)) {   // first meeting with radius / 4
-                cx.ck_put(0, eta_l);
-                cx.ck_put(1, Heta_l);
+                cx.ck_put(0, ec);
+                cx.ck_put(1, hc);
                 cx.ck_put(2, delta);
                 cx.ck_put(3, Hdelta);
-                ck_e_Pe = e_Pe;
+                ck_e_Pe = pc;
                 ck_e_Pd2 = e_Pd2;
                 ck_d_Pd = d_Pd;
                 ck_j = j;
@@ -242,21 +254,31 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
               }
             }
             if (d_Hd <= 0.0 || e_Pe_new >= Delta2) {           // :509
-              const double tau = boundary_tau(e_Pd2, d_Pd, Delta2, e_Pe);           // :514
-              eta_l = fma(tau, delta, eta_l);                       // :516
-              Heta_l = fma(tau, Hdelta, Heta_l);                    // :521
+              const double tau = boundary_tau(e_Pd2, d_Pd, Delta2, pc);             // :514
+              eta_l = fma(tau, delta, ec);                      // :516
+              Heta_l = fma(tau, Hdelta, hc);                    // :521
+              e_Pe_end = pc;
               stop_tCG = (d_Hd <= 0.0) ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;  // :531-534
-              break;
+              return true;
             }
+            // the step's new vectors, for this block only: formed from an opaque copy of alpha so
+            // that they are not merged with (and hoisted above the branch for) the hot path's
+            double alpha_c = alpha;
+            asm volatile("" : "+v"(alpha_c));
             if (beta_p < 1e-3) {
+              const double new_r = fma(alpha_c, Hdelta, r);     // :561
               new_r_r = cx.sum1(new_r * new_r);
               beta = new_r_r / r_r;
             }
             if (j >= p.mininner && new_r_r <= target2) {        // :572
-              e_Pe = e_Pe_new;   // this step passed the radius test (what a rerun has to pass again)
+              e_Pe_end = e_Pe_new;   // this step passed the radius test (what a rerun has to pass again)
               // the reference tests the model of this step first (:552)
+              const double new_eta = fma(alpha_c, delta, ec);   // :538
+              const double new_Heta = fma(alpha_c, Hdelta, hc); // :542
               const double model_new = cx.sum1(new_eta * fma(0.5, new_Heta, g));
               if (model_new >= model_value) {
+                eta_l = ec;
+                Heta_l = hc;
                 stop_tCG = TCG_MODEL_INCREASED;
               } else {
                 eta_l = new_eta;
@@ -264,30 +286,46 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
                 stop_tCG = (p.kappa < nr0_theta) ? TCG_REACHED_TARGET_LINEAR
                                                  : TCG_REACHED_TARGET_SUPERLINEAR;
               }
-              break;
+              return true;
+            }
+            if (j + 1 >= p.maxinner) {
+              // inner iterations exhausted (:495) with the model test of this last step pending:
+              // take the step and reduce its model value on the spot
+              e_Pe_end = e_Pe_new;
+              const double new_eta = fma(alpha_c, delta, ec);   // :538
+              const double new_Heta = fma(alpha_c, Hdelta, hc); // :542
+              const double model_last = cx.sum1(new_eta * fma(0.5, new_Heta, g));
+              if (model_last >= model_value) {
+                eta_l = ec;
+                Heta_l = hc;
+                stop_tCG = TCG_MODEL_INCREASED;
+              } else {
+                eta_l = new_eta;
+                Heta_l = new_Heta;
+              }
+              j = p.maxinner;
+              return true;
             }
           }
-          e_Pe = e_Pe_new;                                  // :537
-          eta_prev = eta_l;
-          Heta_prev = Heta_l;
+          ++j;
+          pn = e_Pe_new;                                    // :537
           model_prev = model_value;
-          eta_l = new_eta;                                    // :556-558
-          Heta_l = new_Heta;
-          r = new_r;                                        // :561
-          w = new_w;
+          en = fma(alpha, delta, ec);                       // :538, :556-558 (over the previous eta)
+          hn = fma(alpha, Hdelta, hc);                      // :542
+          r = fma(alpha, Hdelta, r);                        // :561
+          w = fma(-alpha, Hdelta, w);
           delta = fma(beta, delta, w);                      // :593
           e_Pd2 = beta * fma(alpha + alpha, d_Pd, e_Pd2);   // :596 (carried as 2 <eta, delta>)
           d_Pd = fma(beta * beta, d_Pd, new_r_r);           // :597
-        }
-        if (!bad && j >= p.maxinner) {
-          // inner iterations exhausted with the model test of the last step still pending
-          const double model_last = cx.sum1(eta_l * fma(0.5, Heta_l, g));
-          if (model_last >= model_prev) {
-            eta_l = eta_prev;
-            Heta_l = Heta_prev;
-            stop_tCG = TCG_MODEL_INCREASED;
+          return false;
+        };
+        j = 0;
+        if (p.maxinner > 0)
+          for (;;) {                               // :495
+            if (step(ea, ha, pa, eb, hb, pb)) break;
+            if (step(eb, hb, pb, ea, ha, pa)) break;
           }
-        }
+        const double e_Pe = e_Pe_end;
         last_e_Pe = e_Pe;
         eta = eta_l;
         Heta = Heta_l;
