@@ -161,8 +161,18 @@ def generate_initialization_batch(lb, ub, dim, omega, canonical=False):
     K = np.sum(ev2 > 1e-8, axis=1)
     X = X * (np.arange(N)[None, None, :] < K[:, None, None])
     I, J = np.nonzero(omega)
-    d = X[:, I, :] - X[:, J, :]
-    S = np.einsum("bek,bel->bkl", d, d)
+    # S_b = sum_e d_e d_e^T (linear_projection, dgp.py:174-183) as one GEMM per goal, in slabs that
+    # keep the [slab, E, N] edge differences under ~256 MB (N = 116 has 11208 ordered pairs)
+    S = np.empty((B, N, N))
+    slab = max(1, min(B, int(1.6e7 // max(1, len(I) * N))))
+    di = np.empty((slab, len(I), N))       # reused across slabs (first-touch page faults of fresh
+    dj = np.empty((slab, len(I), N))       # multi-GB temporaries dominated this function at N = 116)
+    for s0 in range(0, B, slab):
+        n = min(slab, B - s0)
+        np.take(X[s0:s0 + n], I, axis=1, out=di[:n])
+        np.take(X[s0:s0 + n], J, axis=1, out=dj[:n])
+        np.subtract(di[:n], dj[:n], out=di[:n])
+        np.matmul(di[:n].transpose(0, 2, 1), di[:n], out=S[s0:s0 + n])
     _, W = np.linalg.eigh(S)
     if canonical:
         W = _canonical_signs(W)
