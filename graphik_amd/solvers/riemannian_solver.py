@@ -233,13 +233,29 @@ class BatchProblem:
                 up[:, a, g] = up[:, g, a] = dist[:, ai]
         return D, lo, up
 
-    def prepare(self, T_goals, chunk=512):
-        """Host pre-processing for a batch: targets [B,T] and Y_init [B,N,k]."""
+    def prepare(self, T_goals, chunk=None, workers=None):
+        """Host pre-processing for a batch: targets [B,T] and Y_init [B,N,k].  Chunks of goals are
+        smoothed and initialised on a thread pool (numpy releases the GIL in its loops and in
+        LAPACK); for graphs the device prepare kernel covers (N <= 32) this path is only the mirror
+        the tests compare it with."""
+        import os
+        from concurrent.futures import ThreadPoolExecutor
         D, lo, up = self.assemble(T_goals)
-        Ys = []
-        for s in range(0, D.shape[0], chunk):
-            lb, ub = dgp.floyd_warshall_bounds(lo[s:s + chunk], up[s:s + chunk])
-            Ys.append(dgp.generate_initialization_batch(lb, ub, self.dim, self.omega))
+        B = D.shape[0]
+        if chunk is None:
+            chunk = 512 if self.N <= 32 else 8
+        spans = [(s, min(s + chunk, B)) for s in range(0, B, chunk)]
+
+        def one(span):
+            lb, ub = dgp.floyd_warshall_bounds(lo[span[0]:span[1]], up[span[0]:span[1]])
+            return dgp.generate_initialization_batch(lb, ub, self.dim, self.omega)
+
+        workers = workers or min(len(spans), max(1, (os.cpu_count() or 1) // 2))
+        if workers <= 1 or len(spans) == 1:
+            Ys = [one(sp) for sp in spans]
+        else:
+            with ThreadPoolExecutor(workers) as ex:
+                Ys = list(ex.map(one, spans))
         return self.template.targets_from_D(D), np.concatenate(Ys, axis=0)
 
     def joint_variables(self, Y, T_goals):
