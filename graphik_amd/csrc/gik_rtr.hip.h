@@ -4,9 +4,12 @@
 // rtr_solve_one<Ctx>() is TrustRegions.solve (graphik/solvers/trust_region.py:112-434) with
 // _truncated_conjugate_gradient (:436-599) inlined, written against a context `Ctx` that owns the
 // problem data and provides
-//     cost(x), commit() -> egrad entry, proj_setup(flag), hess_proj_dot(delta, s, d_Hd, hd),
-//     static sum_n<NV>(v)   (reduction over all unknowns, result uniform in every thread),
-//     pk2[NC], lead()       (the one thread that writes per-problem scalars).
+//     cost(x), commit() -> egrad entry, proj_setup(flag),
+//     k = 3: ehess(delta) -> raw Hessian product entry, Q[3] (orthonormal vertical basis),
+//            ck_put / ck_get (per-thread checkpoint slots in LDS, HAS_CK);
+//     k = 2: hess_proj_dot(delta, s, d_Hd, hd), pk2[NC];
+//     sum_n<NV>(v), sum1(x) (reductions over all unknowns, result uniform in every thread),
+//     lead()                (the one thread that writes per-problem scalars).
 // Every thread holds one entry of each tangent vector (or zero if it owns none).
 #pragma once
 

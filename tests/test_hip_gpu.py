@@ -603,6 +603,24 @@ def test_ur10_table_solve(torch_cuda):
     assert np.linalg.norm(T_sol.trans - d["T_goal"][0][:3, 3]) < 5e-3
 
 
+def test_host_prepare_thread_pool_is_deterministic(torch_cuda):
+    """Graphs beyond the device prepare kernel (N > 32) are pre-processed on a host thread pool:
+    same values whatever the number of workers."""
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    from graphik_amd.utils import table_environment
+    robot, graph = make_graph("ur10")
+    for idx, obs in enumerate(table_environment()):
+        graph.add_spherical_obstacle(f"o{idx}", obs[0], obs[1])
+    prob = BatchProblem(graph, use_limits=True)
+    rng = np.random.RandomState(4)
+    lb, ub = robot.limits_arrays()
+    Tg = robot.fk_batch(lb + (ub - lb) * rng.rand(24, robot.n))
+    t1, y1 = prob.prepare(Tg, workers=1)
+    t4, y4 = prob.prepare(Tg, workers=3)
+    assert np.array_equal(np.asarray(t1), np.asarray(t4)) and np.array_equal(y1, y4)
+    assert y1.shape == (24, graph.number_of_nodes(), 3) and np.all(np.isfinite(y1))
+
+
 def test_ur10_table_drop_in(torch_cuda):
     """experiments/riemannian_example.py flow: load_ur10 + table obstacles + solve_with_riemannian."""
     from graphik_amd.solvers.riemannian_solver import solve_with_riemannian
