@@ -490,6 +490,7 @@ struct gik_template {
   gik::PipeConst pc;
   std::vector<void *> pipe_allocs;
   size_t prep_smem;
+  int prep_waves_per_cu = 8;
   int sweeps;
 };
 static constexpr int kCounterRing = 256;
@@ -737,6 +738,16 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   t->pc = pc;
   t->sweeps = d->jacobi_sweeps > 0 ? d->jacobi_sweeps : 10;
   t->prep_smem = sizeof(double) * ((size_t)5 * N * N + 2 * d->n_anchor + 96) + sizeof(int) * 48;
+  {
+    // the prepare kernel is latency-bound (dependent Jacobi chains, LDS round trips): run as many
+    // resident waves per CU as its registers and LDS allow (a fixed 8 per CU left half of them
+    // unused: planar-10 prepare 2.3 -> see DESIGN 4.2)
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prep_wave_kernel, WAVE, t->prep_smem) != hipSuccess)
+      occ = 8;
+    if (const char *e = getenv("GIK_PREP_WAVES_PER_CU")) occ = atoi(e);   // developer override
+    t->prep_waves_per_cu = std::max(1, std::min(occ, 32));
+  }
   t->has_pipe = true;
   return 0;
 }
@@ -756,7 +767,7 @@ int gik_prepare_batch(const gik_template *t, const double *d_T_goal, int B, doub
   a.K_out = d_K_out;
   a.B = B;
   a.sweeps = t->sweeps;
-  const int grid = std::min(B, t->n_cu * 8);
+  const int grid = std::min(B, t->n_cu * t->prep_waves_per_cu);
   hipLaunchKernelGGL(prep_wave_kernel, dim3(grid), dim3(WAVE), t->prep_smem, (hipStream_t)stream,
                      a);
   HIP_OK(hipGetLastError());
