@@ -85,8 +85,7 @@ def main():
         graph = ProblemGraphPlanar(robot)
     elif args.robot == "ur10_table":
         # BASELINE configs[2]: UR10 + table_environment() (N = 116, 5612 terms): the
-        # workgroup-per-problem solve kernel; goal assembly / joint recovery on the host, outside
-        # the timed region
+        # workgroup-per-goal prepare kernel and the workgroup-per-problem solve kernel
         from graphik_amd.utils import table_environment
         robot, graph = load_ur10()
         for idx, obs in enumerate(table_environment()):
@@ -187,7 +186,7 @@ def main():
                             "pose error); no host work inside the timed region") if on_device else
                            ("RTR solve kernel (workgroup per problem) on targets / Y_init resident in "
                             "HBM; goal assembly and joint recovery run on the host outside the "
-                            "timed region (N > 32)"),
+                            "timed region (graphs beyond the device pipeline, N > 128)"),
                    "parallelism": f"shard{world}", "batches_in_flight": args.streams},
         "median_pos_err_m": float(np.median(pos)), "median_rot_err_rad": float(np.median(rot)),
         "p90_pos_err_m": float(np.percentile(pos, 90)),

@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
       if (r < Kc && c < Kc) {
         for (int p = 0; p < pc.n_pairs; ++p) {
           const int i = pc.pair_i[p], j = pc.pair_j[p];
-          s += (X[i * N + r] - X[j * N + r]) * (X[i * N + c] - X[j * N + c]);
+          s = fma(X[i * N + r] - X[j * N + r], X[i * N + c] - X[j * N + c], s);
         }
       }
       A[e] = 2.0 * s;  // the reference sums both (i,j) and (j,i)
@@ -342,6 +342,306 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
       a.Y_init[(size_t)b * N * K + lane] = s * sg[col];
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// prep_block_kernel: the same pre-processing for graphs beyond one wavefront's LDS (N <= 128, up to
+// 256 anchors: UR10 + table_environment(), N = 116): one 512-thread workgroup per goal, the five
+// N x N matrices in a per-workgroup slab of global memory (L2 / Infinity-Cache resident), the small
+// vectors in LDS.  Same operations in the same order per matrix element as prep_wave_kernel -- the
+// rotations of a Jacobi round act on disjoint index pairs, every other phase is element-wise -- so
+// on a graph both kernels can take the results agree bit for bit (tests).
+constexpr int PREP_NT = 512;
+constexpr int PREP_MAXN = 128;
+constexpr int PREP_MAXA = 256;
+constexpr int PREP_PC = 32;      // pairs per LDS tile of the scatter matrix
+
+__device__ inline double prep_block_sum(double x, double *red, int tid) {
+  x = wave_sum(x);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = x;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < PREP_NT / 64; ++w) s += red[w];
+  return s;
+}
+
+// cyclic Jacobi, round-robin order, block-wide (see jacobi_lds for the arithmetic)
+__device__ inline void jacobi_blk(double *A, double *V, int N, int sweeps, double *cs, int *pq,
+                                  double *red, int tid, int n = -1) {
+  if (n < 0) n = N;
+  const int stride = N;
+  N = n;
+  const int ne = N + (N & 1), np = ne / 2;
+  double fro = 0.0;
+  for (int e = tid; e < N * N; e += PREP_NT) {
+    const int i = e / N, j = e - i * N;
+    const double v = A[i * stride + j];
+    fro = fma(v, v, fro);
+  }
+  const double thr = 1e-16 * sqrt(prep_block_sum(fro, red, tid));
+  for (int sw = 0; sw < sweeps; ++sw) {
+    bool rotated = false;
+    for (int r = 0; r < ne - 1; ++r) {
+      int sig = 0;
+      if (tid < np) {
+        int p, q;
+        rr_pair(ne, r, tid, p, q);
+        double c = 1.0, s = 0.0;
+        int code = -1;
+        if (q < N) {
+          const double apq = A[p * stride + q];
+          if (fabs(apq) > thr) {
+            sig = 1;
+            const double th = (A[q * stride + q] - A[p * stride + p]) * (0.5 * frcp(apq));
+            const double h2 = fma(th, th, 1.0);
+            const double t = (th >= 0.0 ? 1.0 : -1.0) * frcp(fabs(th) + h2 * frsqrt(h2));
+            c = frsqrt(fma(t, t, 1.0));
+            s = t * c;
+            code = p | (q << 8);
+          }
+        }
+        cs[2 * tid] = c;
+        cs[2 * tid + 1] = s;
+        pq[tid] = code;
+      }
+      if (!__syncthreads_or(sig)) continue;   // nothing to rotate in this round
+      rotated = true;
+      // column phase: A's and V's columns p, q of every row
+      // (consecutive threads take the rotations of ONE row: its 2 np entries lie in a few cache
+      // lines, whereas consecutive rows of one column are N doubles apart -- 64 lines per wave)
+      const int per = np * N;
+      for (int it = tid; it < 2 * per; it += PREP_NT) {
+        const int which = it >= per, rem = it - which * per, idx = rem / np, m = rem - idx * np;
+        double *M = which ? V : A;
+        const int code = pq[m];
+        if (code >= 0 && M != nullptr) {
+          const int p = code & 0xff, q = code >> 8;
+          const double c = cs[2 * m], s = cs[2 * m + 1];
+          const double ap = M[idx * stride + p], aq = M[idx * stride + q];
+          M[idx * stride + p] = c * ap - s * aq;
+          M[idx * stride + q] = s * ap + c * aq;
+        }
+      }
+      __syncthreads();
+      // row phase on A: rows p, q of every column
+      for (int it = tid; it < per; it += PREP_NT) {
+        const int m = it / N, idx = it - m * N;
+        const int code = pq[m];
+        if (code >= 0) {
+          const int p = code & 0xff, q = code >> 8;
+          const double c = cs[2 * m], s = cs[2 * m + 1];
+          const double ap = A[p * stride + idx], aq = A[q * stride + idx];
+          A[p * stride + idx] = c * ap - s * aq;
+          A[q * stride + idx] = s * ap + c * aq;
+        }
+      }
+      __syncthreads();
+    }
+    if (!rotated) break;
+  }
+}
+
+__global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double *ws) {
+  __shared__ double gd[2 * PREP_MAXA];
+  __shared__ double cs[2 * (PREP_MAXN / 2)];
+  __shared__ double ev[PREP_MAXN], sg[PREP_MAXN], red[PREP_NT / 64];
+  __shared__ int pq[PREP_MAXN / 2], rk[PREP_MAXN];
+  __shared__ double dl[PREP_PC * PREP_MAXN];    // edge differences of PREP_PC pairs
+  const PipeConst &pc = a.pc;
+  const int N = pc.N, K = pc.K, NN = N * N, tid = threadIdx.x;
+  double *U = ws + (size_t)blockIdx.x * 5 * NN;  // upper bounds -> ub
+  double *L = U + NN;                            // lower bounds
+  double *A = L + NN;                            // work matrix
+  double *V = A + NN;                            // eigenvectors / temp
+  double *X = V + NN;                            // MDS factor
+  const int D = K + 1;
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const double *Tg = a.T_goal + (size_t)b * D * D;
+    double g0[3], g1[3];
+    for (int c = 0; c < K; ++c) {
+      g0[c] = Tg[c * D + K];
+      g1[c] = (K == 3) ? g0[c] + Tg[c * D + 2] * pc.goal_len : g0[c] - Tg[c * D + 0] * pc.goal_len;
+    }
+    for (int e = tid; e < NN; e += PREP_NT) {
+      const double lo = pc.base_lower[e], up = pc.base_upper[e];
+      const bool diag = (e / N) == (e % N);
+      U[e] = diag ? 0.0 : (up == up ? up : INFINITY);
+      L[e] = diag ? 0.0 : (lo == lo ? lo : -INFINITY);
+    }
+    __syncthreads();
+    if (tid < 2 * pc.n_anchor) {
+      const int ai = tid >> 1, gs = tid & 1;
+      double d2 = 0.0;
+      for (int c = 0; c < K; ++c) {
+        const double df = pc.anchor_pos[ai * K + c] - (gs ? g1[c] : g0[c]);
+        d2 += df * df;
+      }
+      const double d = sqrt(d2);   // np.linalg.norm
+      gd[tid] = d;
+      const int an = pc.anchor_idx[ai], gn = gs ? pc.goal1 : pc.goal0;
+      U[an * N + gn] = U[gn * N + an] = d;
+      L[an * N + gn] = L[gn * N + an] = d;
+    }
+    __syncthreads();
+    for (int t = tid; t < pc.T; t += PREP_NT) {
+      const int src = pc.term_src[t];
+      const double g = src >= 0 ? gd[src] : 0.0;
+      a.targets[(size_t)b * pc.T + t] = src >= 0 ? g * g : pc.term_static[t];
+    }
+    // ---- bound smoothing (see prep_wave_kernel)
+    for (int m = 0; m < N; ++m) {
+      for (int e = tid; e < NN; e += PREP_NT) {
+        const int i = e / N, j = e - i * N;
+        const double cand = U[i * N + m] + U[m * N + j];
+        if (cand < U[e]) U[e] = cand;
+      }
+      __syncthreads();
+    }
+    for (int e = tid; e < NN; e += PREP_NT) {  // A[u][b] = max_a (L[a][b] - U[u][a])
+      const int u = e / N, bb = e - u * N;
+      double best = -INFINITY;
+      for (int q = 0; q < N; ++q) best = fmax(best, L[q * N + bb] - U[u * N + q]);
+      A[e] = best;
+    }
+    __syncthreads();
+    for (int e = tid; e < NN; e += PREP_NT) {  // V[u][v] = lb
+      const int u = e / N, v = e - u * N;
+      double best = 0.0;
+      for (int q = 0; q < N; ++q) best = fmax(best, A[u * N + q] - U[q * N + v]);
+      V[e] = best;
+    }
+    __syncthreads();
+    // ---- generate_initialization: D_rand = (lb + 0.9 (ub - lb))^2, Gram = -1/2 J D J
+    for (int e = tid; e < NN; e += PREP_NT) {
+      const double lbv = V[e], d = lbv + 0.9 * (U[e] - lbv);
+      X[e] = d * d;
+    }
+    __syncthreads();
+    if (tid < N) {
+      double s = 0.0;
+      for (int j = 0; j < N; ++j) s += X[tid * N + j];
+      ev[tid] = s / N;
+    }
+    __syncthreads();
+    double mean = 0.0;
+    for (int j = 0; j < N; ++j) mean += ev[j];
+    mean /= N;
+    for (int e = tid; e < NN; e += PREP_NT) {
+      const int i = e / N, j = e - i * N;
+      A[e] = -0.5 * (X[e] - ev[i] - ev[j] + mean);
+      V[e] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid);
+    // ---- factor(): clip, scale by sqrt(lambda), order descending
+    __syncthreads();
+    if (tid < N) ev[tid] = A[tid * N + tid];
+    __syncthreads();
+    if (tid < N) {
+      rk[tid] = desc_rank(ev, N, tid);
+      double big = 0.0, sgn = 1.0;
+      for (int r = 0; r < N; ++r) {
+        const double v = V[r * N + tid];
+        if (fabs(v) > big) {
+          big = fabs(v);
+          sgn = v < 0.0 ? -1.0 : 1.0;
+        }
+      }
+      sg[tid] = sgn * sqrt(fmax(ev[tid], 0.0));
+    }
+    __syncthreads();
+    for (int e = tid; e < NN; e += PREP_NT) {
+      const int r = e / N, c = e - r * N;
+      X[r * N + rk[c]] = V[e] * sg[c];
+    }
+    __syncthreads();
+    // ---- MDS(): K = #eigenvalues > eps of the symmetric matrix read from the LOWER triangle of x
+    for (int e = tid; e < NN; e += PREP_NT) {
+      const int i = e / N, j = e - i * N;
+      A[e] = (i >= j) ? X[i * N + j] : X[j * N + i];
+    }
+    __syncthreads();
+    jacobi_blk(A, nullptr, N, a.sweeps, cs, pq, red, tid);
+    __syncthreads();
+    int Kc = 0;
+    for (int j = 0; j < N; ++j) Kc += A[j * N + j] > 1e-8;
+    if (a.K_out && tid == 0) a.K_out[b] = Kc;
+    __syncthreads();
+    // ---- linear_projection (dgp.py:174-183)
+    for (int e = tid; e < NN; e += PREP_NT) {
+      const int c = e % N;
+      if (c >= Kc) X[e] = 0.0;
+    }
+    __syncthreads();
+    {
+      // S[r][c] = sum_p d_p[r] d_p[c], d_p = X[i_p] - X[j_p]: 5604 pairs x Kc^2 at N = 116, so the
+      // edge differences of 32 pairs at a time are staged in LDS and every thread keeps the
+      // running sums of its <= 32 matrix entries in registers (same order over p as the wave kernel)
+      constexpr int EPT = (PREP_MAXN * PREP_MAXN + PREP_NT - 1) / PREP_NT;   // entries per thread
+      double acc[EPT];
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) acc[q] = 0.0;
+      for (int p0 = 0; p0 < pc.n_pairs; p0 += PREP_PC) {
+        const int np_ = min(PREP_PC, pc.n_pairs - p0);
+        for (int it = tid; it < np_ * Kc; it += PREP_NT) {
+          const int pp = it / Kc, c = it - pp * Kc;
+          const int i = pc.pair_i[p0 + pp], j = pc.pair_j[p0 + pp];
+          dl[pp * PREP_MAXN + c] = X[i * N + c] - X[j * N + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+          const int e = tid + q * PREP_NT;
+          const int r = e / N, c = e - r * N;
+          if (e < NN && r < Kc && c < Kc) {
+            double sacc = acc[q];
+            for (int pp = 0; pp < np_; ++pp)
+              sacc = fma(dl[pp * PREP_MAXN + r], dl[pp * PREP_MAXN + c], sacc);
+            acc[q] = sacc;
+          }
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) {
+        const int e = tid + q * PREP_NT;
+        if (e < NN) {
+          const int r = e / N, c = e - r * N;
+          A[e] = 2.0 * acc[q];  // the reference sums both (i,j) and (j,i)
+          V[e] = (r == c) ? 1.0 : 0.0;
+        }
+      }
+    }
+    __syncthreads();
+    jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid, Kc > 1 ? Kc : 2);
+    __syncthreads();
+    if (tid < N) ev[tid] = (tid < Kc) ? A[tid * N + tid] : -INFINITY;
+    __syncthreads();
+    if (tid < N) {
+      rk[tid] = desc_rank(ev, N, tid);
+      double big = 0.0, sgn = 1.0;
+      for (int r = 0; r < N; ++r) {
+        const double v = V[r * N + tid];
+        if (fabs(v) > big) {
+          big = fabs(v);
+          sgn = v < 0.0 ? -1.0 : 1.0;
+        }
+      }
+      sg[tid] = sgn;
+    }
+    __syncthreads();
+    if (tid < N * K) {   // N * K <= 384
+      const int r = tid / K, dcol = tid - r * K;
+      int col = 0;
+      for (int c = 0; c < N; ++c) col = (rk[c] == dcol) ? c : col;
+      double s = 0.0;
+      for (int c = 0; c < N; ++c) s += X[r * N + c] * V[c * N + col];
+      a.Y_init[(size_t)b * N * K + tid] = s * sg[col];
+    }
+    __syncthreads();
   }
 }
 

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -490,7 +491,12 @@ struct gik_template {
   gik::PipeConst pc;
   std::vector<void *> pipe_allocs;
   size_t prep_smem;
-  int prep_waves_per_cu = 8;
+  int prep_waves_per_cu = 8;   // resident prepare waves (workgroups on the block variant) per CU
+  bool prep_block = false;
+  double *prep_ws = nullptr;   // [n_cu * prep_waves_per_cu][5][N*N] (block variant)
+  hipEvent_t prep_done = nullptr;   // block variant: launches share prep_ws, so each one waits
+  std::mutex prep_mutex;            // for the previous one (whatever stream it ran on)
+  bool prep_pending = false;
   int sweeps;
 };
 static constexpr int kCounterRing = 256;
@@ -693,6 +699,7 @@ void gik_template_destroy(gik_template *t) {
   if (t->d_slot_meta) (void)hipFree(t->d_slot_meta);
   if (t->d_counters) (void)hipFree(t->d_counters);
   for (void *p : t->pipe_allocs) (void)hipFree(p);
+  if (t->prep_done) (void)hipEventDestroy(t->prep_done);
   delete t;
 }
 
@@ -702,7 +709,8 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   if (t->has_pipe) return fail("pipeline already attached");
   const int N = t->N, K = t->K, n = d->n_joints;
   if (n < 1 || n > 31) return fail("n_joints out of range");
-  if (d->n_anchor < 1 || d->n_anchor > 32) return fail("n_anchor must be in [1, 32]");
+  if (d->n_anchor < 1 || d->n_anchor > PREP_MAXA) return fail("n_anchor must be in [1, 256]");
+  if (N > PREP_MAXN) return fail("the device pipeline handles graphs of up to 128 nodes");
   if (!d->T0 || !d->p_index || !d->base_lower || !d->base_upper || !d->anchor_index ||
       !d->anchor_pos || !d->pair_i || !d->pair_j || !d->term_src || !d->term_static)
     return fail("null pipeline array");
@@ -738,7 +746,23 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   t->pc = pc;
   t->sweeps = d->jacobi_sweeps > 0 ? d->jacobi_sweeps : 10;
   t->prep_smem = sizeof(double) * ((size_t)5 * N * N + 2 * d->n_anchor + 96) + sizeof(int) * 48;
-  {
+  // graphs beyond one wavefront's LDS: workgroup-per-goal kernel with its matrices in a global slab
+  t->prep_block = N > 32 || d->n_anchor > 32 || getenv("GIK_PREP_FORCE_BLOCK") != nullptr;  // (env: tests)
+  if (t->prep_block) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prep_block_kernel, PREP_NT, 0) != hipSuccess)
+      occ = 1;
+    occ = std::max(1, std::min(occ, 2));   // 5 N^2 doubles per workgroup: keep the slabs cache-resident
+    if (const char *e = getenv("GIK_PREP_WAVES_PER_CU")) occ = std::max(1, atoi(e));
+    t->prep_waves_per_cu = occ;
+    const size_t bytes = sizeof(double) * 5 * (size_t)N * N * (size_t)t->n_cu * occ;
+    void *ws = nullptr;
+    if (hipMalloc(&ws, bytes) != hipSuccess) return fail("cannot allocate the prepare workspace");
+    t->pipe_allocs.push_back(ws);
+    t->prep_ws = static_cast<double *>(ws);
+    if (hipEventCreateWithFlags(&t->prep_done, hipEventDisableTiming) != hipSuccess)
+      return fail("hipEventCreate failed");
+  } else {
     // the prepare kernel is latency-bound (dependent Jacobi chains, LDS round trips): run as many
     // resident waves per CU as its registers and LDS allow (a fixed 8 per CU left half of them
     // unused: planar-10 prepare 2.3 -> see DESIGN 4.2)
@@ -768,8 +792,17 @@ int gik_prepare_batch(const gik_template *t, const double *d_T_goal, int B, doub
   a.B = B;
   a.sweeps = t->sweeps;
   const int grid = std::min(B, t->n_cu * t->prep_waves_per_cu);
-  hipLaunchKernelGGL(prep_wave_kernel, dim3(grid), dim3(WAVE), t->prep_smem, (hipStream_t)stream,
-                     a);
+  if (t->prep_block) {
+    gik_template *mt = const_cast<gik_template *>(t);   // the workspace hand-over is the mutable part
+    std::lock_guard<std::mutex> lock(mt->prep_mutex);
+    if (mt->prep_pending) HIP_OK(hipStreamWaitEvent((hipStream_t)stream, mt->prep_done, 0));
+    hipLaunchKernelGGL(prep_block_kernel, dim3(grid), dim3(PREP_NT), 0, (hipStream_t)stream, a,
+                       t->prep_ws);
+    HIP_OK(hipEventRecord(mt->prep_done, (hipStream_t)stream));
+    mt->prep_pending = true;
+  } else
+    hipLaunchKernelGGL(prep_wave_kernel, dim3(grid), dim3(WAVE), t->prep_smem, (hipStream_t)stream,
+                       a);
   HIP_OK(hipGetLastError());
   return 0;
 }

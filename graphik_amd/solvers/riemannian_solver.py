@@ -163,8 +163,8 @@ class BatchProblem:
         """Hand the goal-independent pre/post-processing data to the device handle."""
         g, T = self.graph, self.template
         n = self.robot.n
-        if len(self.anchor_nodes) > 32 or self.N > 32:
-            self.device_pipeline = False   # obstacle-laden graphs: host pre/post (block path)
+        if len(self.anchor_nodes) > 256 or self.N > 128:
+            self.device_pipeline = False   # beyond the device prepare kernels: host pre/post
             return
         goalset = set(self.goal_nodes)
         slot = {a: s for s, a in enumerate(self.anchor_nodes)}

@@ -145,7 +145,9 @@ typedef struct {
   double goal_len;           /* axis_length (k=3) / DIST(p_{n-1}, p_n) (k=2)               */
   const double *base_lower;  /* [N*N] LOWER of the goal-independent edges, NaN = no edge   */
   const double *base_upper;  /* [N*N] UPPER                                                */
-  int32_t n_anchor;          /* nodes with a known position besides the goal nodes (<= 32) */
+  int32_t n_anchor;          /* nodes with a known position besides the goal nodes (<= 256;
+                                graphs with N > 32 or more than 32 anchors, up to N = 128, are
+                                prepared by a workgroup-per-goal kernel, same arithmetic)     */
   const int32_t *anchor_index; /* [n_anchor]                                               */
   const double *anchor_pos;  /* [n_anchor][k]                                              */
   int32_t n_pairs;           /* omega pairs (i<j) of the goal graph                        */

@@ -414,7 +414,8 @@ def test_drop_in_single_goal(torch_cuda):
 
 
 # ---- device pre/post-processing (gik_prepare_batch / gik_recover_batch / gik_ik_batch) ----------
-@pytest.mark.parametrize("name", ["lwa4d", "ur10", "kuka", "planar10_limits_halfpi", "planar10_nolimits"])
+@pytest.mark.parametrize("name", ["lwa4d", "ur10", "kuka", "planar10_limits_halfpi", "planar10_nolimits",
+                                  "ur10_table"])
 def test_device_prepare_matches_host(torch_cuda, name):
     """from_pose + bound_smoothing + generate_initialization on the device against the host
     restatement.  Targets and bounds-derived data must agree to 1e-12; Y_init is compared through
@@ -429,7 +430,8 @@ def test_device_prepare_matches_host(torch_cuda, name):
     assert prob.device_pipeline
     rng = np.random.RandomState(3)
     lb_q, ub_q = robot.limits_arrays()
-    Tg = np.concatenate([d["T_goal"], robot.fk_batch(lb_q + (ub_q - lb_q) * rng.rand(112, robot.n))])
+    n_rand = 112 if graph.number_of_nodes() <= 32 else 23      # N = 116 runs the workgroup-per-goal kernel
+    Tg = np.concatenate([d["T_goal"], robot.fk_batch(lb_q + (ub_q - lb_q) * rng.rand(n_rand, robot.n))])
     tg_d, Y_d, K_d = prob.template.prepare(Tg, return_K=True)
     tg_d, Y_d, K_d = tg_d.cpu().numpy(), Y_d.cpu().numpy(), K_d.cpu().numpy()
     D, lo, up = prob.assemble(Tg)
@@ -448,6 +450,28 @@ def test_device_prepare_matches_host(torch_cuda, name):
     same = np.abs(G_d - G_r).reshape(len(Tg), -1).max(axis=1) < 1e-8 * np.abs(G_r).max()
     assert same.mean() > 0.25
     assert np.all(K_d >= graph.dim) and np.all(K_d <= graph.number_of_nodes())
+
+
+@pytest.mark.parametrize("name", ["lwa4d", "planar10_limits_halfpi"])
+def test_block_prepare_kernel_equals_wave_kernel(torch_cuda, monkeypatch, name):
+    """The workgroup-per-goal prepare kernel (graphs beyond one wavefront's LDS) performs the same
+    operations in the same order per matrix element as the wavefront kernel, so on a graph both can
+    take, targets, initial points and MDS ranks agree bit for bit."""
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    robot, graph = make_graph(name)
+    rng = np.random.RandomState(8)
+    lb_q, ub_q = robot.limits_arrays()
+    Tg = robot.fk_batch(lb_q + (ub_q - lb_q) * rng.rand(700, robot.n))    # more goals than workgroups
+    out = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("GIK_PREP_FORCE_BLOCK", "1")
+        prob = BatchProblem(graph, use_limits=True)
+        tg, Y, K = prob.template.prepare(Tg, return_K=True)
+        out.append((tg.cpu().numpy(), Y.cpu().numpy(), K.cpu().numpy()))
+    monkeypatch.delenv("GIK_PREP_FORCE_BLOCK")
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("name", ["lwa4d", "ur10", "kuka", "planar10_limits_halfpi"])
