@@ -28,6 +28,18 @@ struct RtrOut {
   double f, gradnorm;
   int iterations, inner_total, stop, n_accept;
   int inner_executed;   // Hessian products actually evaluated (<= the reference's count, see "Retrace")
+  double Delta;         // trust-region radius at return
+  int paused;           // returned after `slice_its` outer iterations without meeting a stopping rule
+};
+
+// A solve is exactly resumable from (x, Delta, counters): cost, gradient and projector are
+// functions of x alone and are recomputed, the tCG checkpoint is dropped (resuming from it is
+// bit-identical to rerunning tCG anyway).  The persistent kernels use this to time-slice long
+// problems (see rtr_wave_kernel).
+struct RtrResume {
+  double Delta;
+  int kiter, inner_total, inner_exec, n_accept;
+  int resumed;
 };
 
 // ||g||_F together with <g, pk2_m> in one reduction
@@ -60,19 +72,26 @@ __device__ inline double boundary_tau(double e_Pd2, double d_Pd, double Delta2, 
 // norm_r0 ** theta needs no pow().  The generic build evaluates pow() when theta != 1; inlined, its
 // polynomial constants are hoisted to the per-problem setup and spilled to scratch by every problem
 // (measured: +15 MB of HBM writes per 4096-goal launch), so the default path must not contain it.
-template <int K, bool THETA_ONE, typename Ctx>
+// SLICE: compiled with the resume / pause hooks (workgroup-per-problem kernel).  The wave kernel
+// does without: the extra scalar state costs it its last free registers (256 VGPRs + scratch,
+// 972 -> 1114 cycles per iteration), more than time slicing returns there.
+template <int K, bool THETA_ONE, bool SLICE, typename Ctx>
 __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &trace, int has_trace,
-                                     int dbg, double *dbg_buf, int b, double &x, RtrOut &out) {
+                                     int dbg, double *dbg_buf, int b, double &x, RtrOut &out,
+                                     const RtrResume &rs, int slice_its) {
   const double Delta_bar = 10.0 + K;  // typicaldist (fixed_rank_psd_sym.py:71-73)
   const bool lead = cx.lead();
-    double Delta = Delta_bar / 8.0;         // trust_region.py:134-135,164
+    double Delta = (SLICE && rs.resumed) ? rs.Delta : Delta_bar / 8.0;   // trust_region.py:134-135,164
     double fx = cx.cost(x);                 // :159
     double g = cx.commit();                 // :160  (also loads the slot constants at x)
     cx.proj_setup(p.planar_proj_exact);
     // ||grad|| (:161) and rho0_m = <grad, pk2_m> (start values of the tCG recurrences)
     double rho0[Ctx::NC];
     double norm_grad = grad_norm_and_rho(cx, g, rho0);
-    int kiter = 0, inner_total = 0, inner_exec = 0, n_accept = 0, stop = 1;
+    int kiter = SLICE ? rs.kiter : 0, inner_total = SLICE ? rs.inner_total : 0,
+        inner_exec = SLICE ? rs.inner_exec : 0, n_accept = SLICE ? rs.n_accept : 0, stop = 1;
+    int slice_count = 0;
+    bool paused = false;
     // ---- Retrace (k = 3 wave path) --------------------------------------------------------
     // A rejected step leaves x, g and the Hessian unchanged and divides the radius by 4
     // (:336-338, :382), so the reference's next tCG solve repeats the previous one operation for
@@ -465,6 +484,8 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
       if (kiter >= p.maxiter) { stop = 1; break; }
       if (UNI(norm_grad < p.mingradnorm)) { stop = 0; break; }
       if (UNI(!(norm_grad == norm_grad) || !(fx == fx))) { bad = true; break; }
+      if constexpr (SLICE)
+        if (slice_its > 0 && ++slice_count >= slice_its) { paused = true; break; }
     }
     if (bad) stop = 2;
     if (prof && lead) {
@@ -481,6 +502,8 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
     out.inner_executed = inner_exec;
     out.stop = stop;
     out.n_accept = n_accept;
+    out.Delta = Delta;
+    out.paused = paused ? 1 : 0;
 }
 
 }  // namespace gik

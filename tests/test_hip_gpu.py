@@ -331,6 +331,36 @@ def test_checkpoint_resume_is_bit_identical(torch_cuda, monkeypatch, name):
     assert a["inner_executed"].sum() < 0.95 * b["inner_executed"].sum()   # measured: -11 ... -14 %
 
 
+def test_time_slicing_is_bit_identical(torch_cuda, monkeypatch):
+    """The workgroup-per-problem kernel re-queues a problem that has not met a stopping rule after
+    GIK_SLICE outer iterations (default 256) behind everything that is waiting, so that the long
+    problems of a batch do not start last.  A solve is exactly resumable from (x, Delta,
+    counters), so the results must not depend on the slice length; only the executed work may (the
+    tCG checkpoint is dropped at a slice boundary)."""
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    from graphik_amd.engine import Template
+    robot, graph = make_graph("lwa4d")
+    prob = BatchProblem(graph, use_limits=True)
+    rng = np.random.RandomState(12)
+    Tg = robot.fk_batch(-np.pi + 2 * np.pi * rng.rand(600, robot.n))     # more problems than workgroups
+    targets, Y0 = prob.prepare(Tg)
+    tpl = Template.from_matrices(prob.omega, prob.psi_L, prob.psi_U, k=3, use_limits=True,
+                                 params={"force_block_path": 1})
+    keys = ("x", "f", "gradnorm", "iterations", "inner_total", "stop", "n_accept")
+    runs = {}
+    for sl in ("0", "256", "24"):
+        monkeypatch.setenv("GIK_SLICE", sl)
+        r = tpl.solve(Y0, targets, trace_cap=40)
+        runs[sl] = {k: r[k].cpu().numpy() for k in keys + ("inner_executed",)}
+        runs[sl]["numit"] = r["trace"]["numit"].cpu().numpy()
+    monkeypatch.delenv("GIK_SLICE")
+    assert (runs["0"]["iterations"] > 256).sum() > 20          # problems that do get re-queued
+    for sl in ("256", "24"):
+        for k in keys + ("numit",):
+            assert np.array_equal(runs["0"][k], runs[sl][k], equal_nan=True), (sl, k)
+        assert runs[sl]["inner_executed"].sum() >= runs["0"]["inner_executed"].sum()
+
+
 def test_results_independent_of_persistent_grid(torch_cuda, monkeypatch):
     """The solve kernel is persistent (waves claim problems from a queue); the number of resident
     waves is a scheduling choice (one or two per SIMD, gik_solve_batch) and must not change a
