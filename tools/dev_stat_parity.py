@@ -25,3 +25,6 @@ for name, loader in (("lwa4d", load_schunk_lwa4d), ("kuka", load_kuka), ("ur10",
         name, B, time.time() - t0, np.mean(f_g < 1e-9), np.mean(f_o < 1e-9), np.mean((f_g < 1e-9) == (f_o < 1e-9)),
         np.median(its_g), np.median(its_o), np.percentile(its_g, 90), np.percentile(its_o, 90),
         np.median(hv_g), np.median(hv_o), hv_g.mean(), hv_o.mean(), np.mean(its_g >= 3000), np.mean(its_o >= 3000)))
+    ex_g = r["inner_executed"].cpu().numpy()
+    print("      Hessian products EXECUTED on the GPU (checkpoint resume): mean %.0f = %.3f of the oracle's count; slowest problem %d executed / %d counted (oracle max %d)" % (
+        ex_g.mean(), ex_g.mean() / hv_o.mean(), ex_g[np.argmax(hv_g)], hv_g.max(), hv_o.max()))
