@@ -577,43 +577,41 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
     }
     __syncthreads();
     {
-      // S[r][c] = sum_p d_p[r] d_p[c], d_p = X[i_p] - X[j_p]: 5604 pairs x Kc^2 at N = 116, so the
-      // edge differences of 32 pairs at a time are staged in LDS and every thread keeps the
-      // running sums of its <= 32 matrix entries in registers (same order over p as the wave kernel)
-      constexpr int EPT = (PREP_MAXN * PREP_MAXN + PREP_NT - 1) / PREP_NT;   // entries per thread
-      double acc[EPT];
+      // S[r][c] = sum_p d_p[r] d_p[c], d_p = X[i_p] - X[j_p]: 5604 pairs x Kc^2 at N = 116.  The
+      // edge differences of 32 pairs at a time are staged in LDS; a thread owns row r = tid / 4 and
+      // every fourth column from tid % 4, so that one LDS read of d_p[r] serves all its entries
+      // and the running sums sit in registers with constant indices (same order over p per entry
+      // as the wave kernel; columns >= Kc of X are zero, so the whole N x N matrix is formed)
+      constexpr int CPT = PREP_MAXN / 4;   // columns per thread
+      const int r = tid >> 2, c0 = tid & 3;
+      double acc[CPT];
 #pragma unroll
-      for (int q = 0; q < EPT; ++q) acc[q] = 0.0;
+      for (int q = 0; q < CPT; ++q) acc[q] = 0.0;
       for (int p0 = 0; p0 < pc.n_pairs; p0 += PREP_PC) {
         const int np_ = min(PREP_PC, pc.n_pairs - p0);
-        for (int it = tid; it < np_ * Kc; it += PREP_NT) {
-          const int pp = it / Kc, c = it - pp * Kc;
-          const int i = pc.pair_i[p0 + pp], j = pc.pair_j[p0 + pp];
-          dl[pp * PREP_MAXN + c] = X[i * N + c] - X[j * N + c];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) {
-          const int e = tid + q * PREP_NT;
-          const int r = e / N, c = e - r * N;
-          if (e < NN && r < Kc && c < Kc) {
-            double sacc = acc[q];
-            for (int pp = 0; pp < np_; ++pp)
-              sacc = fma(dl[pp * PREP_MAXN + r], dl[pp * PREP_MAXN + c], sacc);
-            acc[q] = sacc;
+        for (int it = tid; it < np_ * PREP_MAXN; it += PREP_NT) {
+          const int pp = it / PREP_MAXN, c = it - pp * PREP_MAXN;
+          double dv = 0.0;
+          if (c < N) {
+            const int i = pc.pair_i[p0 + pp], j = pc.pair_j[p0 + pp];
+            dv = X[i * N + c] - X[j * N + c];
           }
+          dl[it] = dv;
+        }
+        __syncthreads();
+        for (int pp = 0; pp < np_; ++pp) {
+          const double dr = dl[pp * PREP_MAXN + r];
+#pragma unroll
+          for (int q = 0; q < CPT; ++q) acc[q] = fma(dr, dl[pp * PREP_MAXN + c0 + 4 * q], acc[q]);
         }
         __syncthreads();
       }
 #pragma unroll
-      for (int q = 0; q < EPT; ++q) {
-        const int e = tid + q * PREP_NT;
-        if (e < NN) {
-          const int r = e / N, c = e - r * N;
-          A[e] = 2.0 * acc[q];  // the reference sums both (i,j) and (j,i)
-          V[e] = (r == c) ? 1.0 : 0.0;
-        }
+      for (int q = 0; q < CPT; ++q) {
+        const int c = c0 + 4 * q;
+        if (r < N && c < N) A[r * N + c] = 2.0 * acc[q];  // the reference sums both (i,j) and (j,i)
       }
+      for (int e = tid; e < NN; e += PREP_NT) V[e] = ((e / N) == (e % N)) ? 1.0 : 0.0;
     }
     __syncthreads();
     jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid, Kc > 1 ? Kc : 2);
