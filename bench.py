@@ -1,18 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- IK solves/s of the MI355X-native GraphIK RiemannianSolver path.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5]
 
-Workload (BASELINE.json configs[1]): Schunk LWA4D (N=18 graph nodes, k=3, 75 residual terms),
-4096 random goals per GPU (weak scaling), goals = FK of uniform random configurations in
-[-pi, pi]^7 exactly as the reference's examples draw them (robot.random_configuration()).
-One "step" = one pass of the hot path over one batch with its inputs resident in HBM.
-Prints ONE JSON line (rank 0).
+`--gpus N` with N > 1 brings up N ranks itself (it re-executes this file under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, one
+process per GPU, RCCL); started under an external torch.distributed.run it uses the environment
+that launcher provides.
+
+Workloads (BASELINE.json `configs`; goals = FK of uniform random configurations within the joint
+limits, drawn exactly as the reference's examples draw them -- robot.random_configuration()):
+  c2 (default, the bench line)  Schunk LWA4D, 4096 goals per GPU (weak scaling)
+  c3  UR10 + table_environment(), 4096 goals per GPU (weak scaling)
+  c4  KUKA iiwa, 65536 goals sharded contiguously over the GPUs (strong scaling)
+  c5  10-link planar chain, 65536 goals sharded contiguously over the GPUs (strong scaling)
+One "step" = one pass of the hot path over the rank's shard with its inputs resident in HBM.
+Goals are independent: no data-path collective, ONE gather of the per-problem results at the end.
+Rank 0 prints ONE JSON line.
+
+`--dry-solve` (CPU, `--backend gloo`) replaces the device solve by a deterministic per-goal stand-in
+so that the rank / shard / gather logic can be tested without a GPU; its line carries
+"dry_solve": true and no throughput.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,12 +35,15 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import torch  # noqa: E402
-
-from graphik_amd import distributed as gd  # noqa: E402
-
 FP64_PEAK_TFLOPS = 78.6   # MI355X vector = matrix fp64 peak (spec; fp32 vector 157.3 / 2)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
+
+CONFIGS = {   # name -> (robot, goals, "per_gpu" | "total", BASELINE.json configs index)
+    "c2": ("lwa4d", 4096, "per_gpu", 1),
+    "c3": ("ur10_table", 4096, "per_gpu", 2),
+    "c4": ("kuka", 65536, "total", 3),
+    "c5": ("planar10", 65536, "total", 4),
+}
 
 
 def algorithmic_flops(N, k, T, n_inner, n_outer, n_accept):
@@ -43,71 +60,202 @@ def algorithmic_bytes(N, k, T):
     return 8 * (T + 2 * N * k) + 32
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=0,
-                    help="goals per GPU (default 4096; 256 for ur10_table, whose goal assembly runs "
-                         "on the host)")
-    ap.add_argument("--robot", default="lwa4d",
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="BASELINE.json workload (default c2 = configs[1], the bench line)")
+    ap.add_argument("--robot", default=None,
                     choices=["lwa4d", "ur10", "kuka", "planar10", "planar10_halfpi", "ur10_table"],
-                    help="lwa4d = BASELINE configs[1] (the bench line); the others are the parity "
-                         "configs, runnable here for reference numbers")
+                    help="parity configs outside BASELINE's list (overrides --config's robot)")
+    ap.add_argument("--batch", type=int, default=0, help="goals per GPU (overrides the config's size)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="problems for the CPU baseline (0=auto)")
     ap.add_argument("--streams", type=int, default=1,
-                    help="batches in flight: steps are issued round-robin on this many HIP streams, so the "
-                         "straggler tail of one batch overlaps with the bulk of the next (serving mode; "
-                         "the default 1 runs the steps back to back and is the headline configuration)")
-    args = ap.parse_args()
+                    help="batches in flight in the TIMED region (default 1: steps back to back, the "
+                         "headline configuration)")
+    ap.add_argument("--serving-streams", type=int, default=4,
+                    help="extra, separately labelled measurement after the timed region: the same "
+                         "batches issued round-robin on this many HIP streams (0 = skip)")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"])
+    ap.add_argument("--dry-solve", action="store_true",
+                    help="no GPU: deterministic stand-in for the solve (tests of the N>1 logic)")
+    return ap.parse_args(argv)
 
-    rank, local_rank, world = gd.init_process_group()
-    assert world == args.gpus or world == 1 and args.gpus == 1, (world, args.gpus)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
+def self_launch(args):
+    """--gpus N > 1 outside a launcher: one rank per GPU under torch.distributed.run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def build_graph(robot_name):
     from graphik_amd.utils.roboturdf import load_schunk_lwa4d, load_ur10, load_kuka
-    from graphik_amd.solvers.riemannian_solver import BatchProblem
-    if args.robot.startswith("planar10"):
+    if robot_name.startswith("planar10"):
         from graphik_amd.robots import RobotPlanar
         from graphik_amd.graphs import ProblemGraphPlanar
         from graphik_amd.utils import list_to_variable_dict
         nl = 10
-        lim = np.array(9 * [np.pi / 2] + [np.pi]) if args.robot.endswith("halfpi") else np.pi * np.ones(nl)
+        lim = np.array(9 * [np.pi / 2] + [np.pi]) if robot_name.endswith("halfpi") else np.pi * np.ones(nl)
         robot = RobotPlanar({"link_lengths": list_to_variable_dict(np.ones(nl)),
                              "theta": list_to_variable_dict(np.zeros(nl)),
                              "joint_limits_upper": list_to_variable_dict(lim),
                              "joint_limits_lower": list_to_variable_dict(-lim), "num_joints": nl})
-        graph = ProblemGraphPlanar(robot)
-    elif args.robot == "ur10_table":
+        return robot, ProblemGraphPlanar(robot)
+    if robot_name == "ur10_table":
         # BASELINE configs[2]: UR10 + table_environment() (N = 116, 5612 terms): the
         # workgroup-per-goal prepare kernel and the workgroup-per-problem solve kernel
         from graphik_amd.utils import table_environment
         robot, graph = load_ur10()
         for idx, obs in enumerate(table_environment()):
             graph.add_spherical_obstacle(f"o{idx}", obs[0], obs[1])
-    else:
-        robot, graph = {"lwa4d": load_schunk_lwa4d, "ur10": load_ur10, "kuka": load_kuka}[args.robot]()
-    prob = BatchProblem(graph, use_limits=True, device=dev)
-    B = args.batch or (256 if args.robot == "ur10_table" else 4096)
-    N, k, T, n = graph.number_of_nodes(), graph.dim, prob.template.T, robot.n
+        return robot, graph
+    return {"lwa4d": load_schunk_lwa4d, "ur10": load_ur10, "kuka": load_kuka}[robot_name]()
 
-    # synthetic goals: rank r draws rows [r*B, (r+1)*B) of one global stream
+
+def workload(args, world):
+    """(config name, robot name, goals of the whole job, scaling)"""
+    cfg = args.config or ("c2" if args.robot is None else None)
+    if cfg is not None:
+        robot_name, goals, mode, _ = CONFIGS[cfg]
+    else:
+        robot_name, goals, mode = args.robot, 4096, "per_gpu"
+    if args.robot is not None:
+        robot_name = args.robot
+    if args.batch:
+        goals, mode = args.batch, "per_gpu"
+    total = goals * world if mode == "per_gpu" else goals
+    return cfg, robot_name, total, ("weak" if mode == "per_gpu" else "strong")
+
+
+def dry_results(T_goal):
+    """Deterministic per-goal stand-in for [pos_err, rot_err, iterations, inner_total, n_accept,
+    stop, inner_executed] (--dry-solve): a function of the goal pose alone, so the gathered table
+    must equal the single-process one row for row."""
+    flat = T_goal.reshape(len(T_goal), -1)
+    key = np.abs(flat).sum(axis=1)
+    its = 1.0 + np.floor(997.0 * (key - np.floor(key)))
+    return np.stack([1e-4 * key, 1e-4 * (key + 1.0), its, 40.0 * its, np.floor(0.8 * its),
+                     np.zeros_like(key), 38.0 * its], axis=1)
+
+
+def cpu_baseline(prob, T_goal, Y0_h, B, args):
+    """The oracle (C restatement, -O3 AVX2+FMA, OpenMP over problems) timed on this host: one
+    thread on a small sample and every usable core on >= 32 goals per thread (capped at the batch).
+    Hessian products per second per thread are tail-free and are what to compare machines by."""
+    from oracle import c_oracle as co
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:   # a cgroup CPU quota can be far below the affinity mask
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
+    cores = max(1, min(usable, int(quota)) if quota else usable)
+
+    def run(ns, nthreads):
+        D, _, _ = prob.assemble(T_goal[:ns])
+        t0 = time.perf_counter()
+        o = co.rtr_solve_batch(Y0_h[:ns], D, prob.omega, prob.psi_L, prob.psi_U, True,
+                               nthreads=nthreads, fast=True)
+        dt = time.perf_counter() - t0
+        return dt, int(o["inner_total"].sum())
+
+    big = prob.N * prob.dim > 64            # table scene: ~1 s per solve per thread
+    n1 = min(B, 2 if big else 24)
+    t1, hv1 = run(n1, 1)
+    ns = args.cpu_sample or min(B, 2 * cores if big else max(64, 32 * cores))
+    tc, hvc = run(ns, cores)
+    return {
+        "value": ns / tc, "unit": "solves/s", "cores": cores, "kind": "port",
+        "sample": f"first {ns} goals of rank 0's batch ({ns / cores:.1f} per thread), "
+                  f"oracle/gik_oracle.c (-O3 AVX2+FMA), OpenMP dynamic schedule over problems, "
+                  f"{tc:.1f} s wall",
+        "hv_total": hvc, "hv_per_s_per_thread": hvc / tc / cores,
+        "single_thread": {"value": n1 / t1, "unit": "solves/s", "sample": f"first {n1} goals, {t1:.1f} s",
+                          "hv_per_s": hv1 / t1},
+        "effective_parallelism": (hvc / tc) / (hv1 / t1),
+        "host": {"os_cpu_count": os.cpu_count(), "sched_affinity": usable, "cgroup_cpu_quota": quota},
+    }
+
+
+def main():
+    args = parse_args()
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(self_launch(args))
+
+    import torch
+    from graphik_amd import distributed as gd
+
+    backend = args.backend or ("gloo" if args.dry_solve else None)
+    rank, local_rank, world = gd.init_process_group(backend=backend)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); "
+                         f"run `python bench.py --gpus {args.gpus}` (self-launching) or "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py "
+                         f"--gpus {args.gpus}`")
+    dry = args.dry_solve
+    if not dry:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
+
+    cfg, robot_name, total, scaling = workload(args, world)
+    robot, graph = build_graph(robot_name)
+    n = robot.n
+    lo, hi = gd.shard_range(total, rank, world)        # contiguous shard of the global goal stream
+    B = hi - lo
     rs = np.random.RandomState(args.seed)
-    U = rs.rand(world * B, n)[rank * B:(rank + 1) * B]
+    U = rs.rand(total, n)[lo:hi]
     lb, ub = robot.limits_arrays()
-    Q = lb + (ub - lb) * U
-    T_goal = robot.fk_batch(Q)
+    T_goal = robot.fk_batch(lb + (ub - lb) * U)
+
+    if dry:
+        for _ in range(args.warmup):
+            st = dry_results(T_goal)
+        gd.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st = dry_results(T_goal)
+        gd.barrier()
+        dt = gd.max_over_ranks(time.perf_counter() - t0, dev)
+        allstats = gd.gather_rows(torch.from_numpy(st), total, dst=0)
+        gd.shutdown()
+        if rank == 0:
+            a = allstats.numpy()
+            print(json.dumps({
+                "metric": "IK solves/sec (batched random goals)", "value": None, "unit": "solves/s",
+                "dry_solve": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": dt / args.steps * 1e3, "scaling": scaling,
+                "config": {"workload": f"{robot_name}, {total} goals over {world} rank(s)",
+                           "config": cfg, "robot": robot_name, "goals_total": total},
+                "rows": int(a.shape[0]), "checksum": float(a.sum()),
+                "rows_sha": __import__("hashlib").sha256(np.ascontiguousarray(a).tobytes()).hexdigest(),
+            }), flush=True)
+        return
+
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    prob = BatchProblem(graph, use_limits=True, device=dev)
+    N, k, T = graph.number_of_nodes(), graph.dim, prob.template.T
     tpl = prob.template
     on_device = prob.device_pipeline
     Tg_dev = torch.from_numpy(T_goal).to(dev)        # inputs resident in HBM
-    if on_device:
-        bufs = tpl.alloc_ik_buffers(B)
-    else:
+    if not on_device:
         tg_h, Y0_h0 = prob.prepare(T_goal)
         tg_dev, Y0_dev = torch.from_numpy(tg_h).to(dev), torch.from_numpy(Y0_h0).to(dev)
     torch.cuda.synchronize(dev)
@@ -147,6 +295,32 @@ def main():
     dt_local = time.perf_counter() - t0
     dt = gd.max_over_ranks(dt_local, dev)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+
+    # Serving configuration, reported separately (NOT `value`): the same batches, S in flight on
+    # separate HIP streams, so the straggler tail of one batch overlaps with the bulk of the next.
+    serving = None
+    S = args.serving_streams
+    if S > 1 and args.streams == 1 and dt / args.steps < 0.5:   # (skipped for multi-second batches)
+        nb = max(4 * S, 8)
+        sv_streams = [torch.cuda.Stream(dev) for _ in range(S)]
+        for s_ in sv_streams:                        # warm the per-stream allocations
+            with torch.cuda.stream(s_):
+                step()
+        torch.cuda.synchronize(dev)
+        gd.barrier()
+        ts = time.perf_counter()
+        for i in range(nb):
+            with torch.cuda.stream(sv_streams[i % S]):
+                step()
+        torch.cuda.synchronize(dev)
+        gd.barrier()
+        dts = gd.max_over_ranks(time.perf_counter() - ts, dev)
+        serving = {"value": total * nb / dts, "unit": "solves/s", "batches_in_flight": S,
+                   "batches": nb, "ms_per_batch": dts / nb * 1e3,
+                   "note": "same workload and kernels as `value`; S batches in flight on separate HIP "
+                           "streams (a serving configuration: independent requests overlap, the "
+                           "straggler tail of one batch runs beside the bulk of the next)"}
+
     if not on_device:   # host post-processing, after the timed region
         qh = prob.joint_variables(res["x"].cpu().numpy(), T_goal)
         pe, re = prob.pose_errors(qh, T_goal)
@@ -155,15 +329,15 @@ def main():
     # single gather of the per-problem results at the end (RCCL over xGMI when N > 1)
     stats_local = torch.stack([res["pos_err"], res["rot_err"], res["iterations"].double(),
                                res["inner_total"].double(), res["n_accept"].double(),
-                               res["stop"].double()], dim=1)
-    allstats = gd.gather_rows(stats_local, world * B, dst=0)
+                               res["stop"].double(), res["inner_executed"].double()], dim=1)
+    allstats = gd.gather_rows(stats_local, total, dst=0)
     Y0_h = res["Y0"].cpu().numpy()
 
     if rank != 0:
         gd.shutdown()
         return
     st = allstats.cpu().numpy()
-    pos, rot, its, inner, nacc, stop = st.T
+    pos, rot, its, inner, nacc, stop, execd = st.T
     inner_local = float(res["inner_total"].double().sum())        # as the reference counts them
     exec_local = float(res["inner_executed"].double().sum())      # Hessian products evaluated
     outer_local = float(res["iterations"].double().sum())
@@ -171,16 +345,19 @@ def main():
     flops = algorithmic_flops(N, k, T, exec_local, outer_local, acc_local)   # executed work only
     achieved_tf = flops / (kernel_ms * 1e-3) / 1e12
     hbm_bytes = algorithmic_bytes(N, k, T) * B
-    value = world * B * args.steps / dt
+    value = total * args.steps / dt
+    base_idx = CONFIGS[cfg][3] if cfg else None
     out = {
         "metric": "IK solves/sec (batched random goals)",
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.robot} N={N} k={k} terms={T}, {B} random goals per GPU "
-                               "(" + ("BASELINE configs[1]" if args.robot == "lwa4d" else "parity config") + "), reference solver defaults "
-                               "(mingradnorm 5e-10, maxiter 3000)",
-                   "robot": args.robot, "batch_per_gpu": B, "seed": args.seed,
+        "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{robot_name} N={N} k={k} terms={T}, {total} random goals "
+                               f"({B} on rank 0; " +
+                               (f"BASELINE configs[{base_idx}]" if base_idx is not None else "parity config")
+                               + "), reference solver defaults (mingradnorm 5e-10, maxiter 3000)",
+                   "config": cfg, "robot": robot_name, "goals_total": total, "batch_per_gpu": B,
+                   "seed": args.seed,
                    "step": ("goal poses (HBM) -> prepare kernel (goal distances, bound smoothing, "
                             "MDS init) -> RTR solve kernel -> recover kernel (joint angles, FK "
                             "pose error); no host work inside the timed region") if on_device else
@@ -199,42 +376,38 @@ def main():
                                 "step resumes from a checkpoint, bit-identical result); roofline "
                                 "flops use executed"},
         "frac_maxiter": float(np.mean(stop == 1)),
-        "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
+        "roofline": {"bound": "fp64-valu", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": None,
                      "kernel": (f"rtr_wave_kernel<{k},{prob.template.maxdeg}>" if N * k <= 64
                                 else f"rtr_block_kernel<{k}>"), "kernel_ms": kernel_ms,
                      "kernel_share_of_step": kernel_ms / (dt_local / args.steps * 1e3),
                      "flops_per_launch": flops,
-                     "note": "fp64; the solve is LDS/register resident and bound by the instruction "
-                             "issue rate of one wavefront per problem (and, at this batch size, by "
-                             "the slowest problem), not by HBM or MFMA (SURVEY 8(d), DESIGN 4.1); "
+                     "note": "fp64 vector ALU (the contract's \"mfma\" class: compute-bound, not HBM); "
+                             "the solve is LDS/register resident and bound by the instruction issue "
+                             "rate of one wavefront per problem (and, at this batch size, by the "
+                             "slowest problem), not by HBM or MFMA (SURVEY 8(d), DESIGN 4.1); "
                              "peak = MI355X fp64 vector/matrix spec"},
         "roofline_hbm": {"bound": "hbm", "achieved": hbm_bytes / (kernel_ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "bytes_per_launch": hbm_bytes},
     }
+    if serving is not None:
+        out["serving"] = serving
     traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json")
-    if os.path.exists(traffic_file) and args.robot == "lwa4d" and B == 4096:   # profiled workload only
+    if os.path.exists(traffic_file) and robot_name == "lwa4d" and B == 4096:   # profiled workload only
         try:
-            out["roofline"]["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
+            tj = json.load(open(traffic_file))
+            out["roofline"]["traffic"] = tj.get("bytes_per_launch")
+            out["roofline"]["traffic_source"] = ("profiles/hbm_traffic.json: rocprofv3 --pmc passes of "
+                                                 "this command in a separate run (" +
+                                                 str(tj.get("source", "see profiles/README")) + "), not "
+                                                 "measured by the process that printed this line")
         except Exception:
             pass
 
-    if not args.no_cpu_baseline and world == 1:   # rank 0, single-GPU runs only
-        from oracle import c_oracle as co
-        cores = os.cpu_count() or 1
-        ns = args.cpu_sample or min(B, max(32, 8 * cores))
-        D, _, _ = prob.assemble(T_goal[:ns])
-        t0 = time.perf_counter()
-        o = co.rtr_solve_batch(Y0_h[:ns], D, prob.omega, prob.psi_L, prob.psi_U, True,
-                               nthreads=cores, fast=True)
-        tc = time.perf_counter() - t0
-        out["cpu_baseline"] = {
-            "value": ns / tc, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": f"first {ns} goals of rank 0's batch, oracle/gik_oracle.c (-O3 AVX2+FMA), "
-                      f"OpenMP over problems, {tc:.1f} s wall",
-            "hv_total": int(o["inner_total"].sum())}
+    if not args.no_cpu_baseline and world == 1 and prob.psi_L is not None:   # rank 0, single-GPU runs
+        out["cpu_baseline"] = cpu_baseline(prob, T_goal, Y0_h, B, args)
     gd.shutdown()
     print(json.dumps(out), flush=True)
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GIK_LIB_PATH") or os.path.join(_HERE, "lib", "libgraphik_amd.so")
 
 TERM_EQ, TERM_LOWER, TERM_UPPER = 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class TemplateDesc(C.Structure):
@@ -27,12 +27,22 @@ class TemplateDesc(C.Structure):
         ("mininner", C.c_int32), ("theta", C.c_double), ("kappa", C.c_double),
         ("rho_prime", C.c_double), ("rho_regularization", C.c_double),
         ("planar_proj_exact", C.c_int32), ("force_block_path", C.c_int32),
+        ("waves_per_cu", C.c_int32), ("slice_outer_its", C.c_int32), ("debug_flags", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
 class Stats(C.Structure):
+    """gik_stats (40 bytes per problem); engine.py sizes and decodes the stats buffer from this."""
     _fields_ = [("f", C.c_double), ("gradnorm", C.c_double), ("iterations", C.c_int32),
-                ("inner_total", C.c_int32), ("stop", C.c_int32), ("n_accept", C.c_int32)]
+                ("inner_total", C.c_int32), ("stop", C.c_int32), ("n_accept", C.c_int32),
+                ("inner_executed", C.c_int32), ("reserved", C.c_int32)]
+
+
+STATS_BYTES = C.sizeof(Stats)
+# column of each int32 field when the [B, STATS_BYTES / 8] fp64 stats buffer is viewed as int32
+STATS_I32 = {name: getattr(Stats, name).offset // 4 for name, ct in Stats._fields_ if ct is C.c_int32}
+STATS_F64 = {name: getattr(Stats, name).offset // 8 for name, ct in Stats._fields_ if ct is C.c_double}
 
 
 class Trace(C.Structure):
@@ -53,6 +63,7 @@ class PipelineDesc(C.Structure):
         ("n_pairs", C.c_int32), ("pair_i", C.POINTER(C.c_int32)), ("pair_j", C.POINTER(C.c_int32)),
         ("term_src", C.POINTER(C.c_int32)), ("term_static", C.POINTER(C.c_double)),
         ("last_link_along_z", C.c_int32), ("jacobi_sweeps", C.c_int32),
+        ("force_block_prepare", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

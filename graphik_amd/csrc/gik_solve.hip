@@ -346,7 +346,10 @@ __global__ void __launch_bounds__(BLOCK_NT) kat_block_kernel(KatArgs a, int SL, 
 }
 
 // ------------------------------------------------------------------------------------------
-// developer micro-benchmark: per-component cycle cost of one wavefront (not part of the ABI)
+// developer micro-benchmark: per-component cycle cost of one wavefront.  Only in the -DGIK_DEV
+// build (graphik_amd/build.py --dev -> lib/exp/libgraphik_amd_dev.so); the shipped library has
+// neither this kernel nor the gik_debug_* hooks.
+#ifdef GIK_DEV
 template <int K, int MAXDEG>
 __global__ void __launch_bounds__(WAVE) parts_kernel(const uint32_t *slot_meta, int N, int T, int mode,
                                                      int iters, double *out) {
@@ -525,10 +528,13 @@ __global__ void __launch_bounds__(WAVE) parts_kernel(const uint32_t *slot_meta, 
     out[1] = acc + sc;
   }
 }
+#endif  // GIK_DEV
 
 // ------------------------------------------------------------------------------------------
 thread_local std::string g_err;
+#ifdef GIK_DEV
 static double *g_dbg_buf = nullptr;
+#endif
 static int fail(const std::string &m) {
   g_err = m;
   return -1;
@@ -584,6 +590,10 @@ struct gik_template {
   unsigned next_slice = 0;
   int device;
   int n_cu;
+  // scheduling knobs, fixed at creation (descriptor fields, overridden once by the environment)
+  int dbg;            // SolveArgs::dbg
+  int wpc_override;   // persistent waves per CU, 0 = automatic
+  int slice_its;      // time slice of the block kernel in outer iterations, 0 = off
   int waves_per_cu;  // resident solve wavefronts per CU (from the occupancy query)
   size_t smem_bytes;
   bool is_block;  // workgroup-per-problem path
@@ -640,6 +650,10 @@ void gik_default_params(gik_template_desc *d) {
   d->rho_regularization = 1e3;  // trust_region.py:92
   d->planar_proj_exact = 0;
   d->force_block_path = 0;
+  d->waves_per_cu = 0;
+  d->slice_outer_its = -1;
+  d->debug_flags = 0;
+  d->reserved0 = 0;
 }
 
 int gik_template_create(const gik_template_desc *d, gik_template **out) {
@@ -743,6 +757,13 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   t->p.maxinner = d->maxinner;
   t->p.mininner = d->mininner;
   t->p.planar_proj_exact = d->planar_proj_exact;
+  t->dbg = d->debug_flags;
+  t->wpc_override = std::max(0, d->waves_per_cu);
+  t->slice_its = d->slice_outer_its < 0 ? 256 : d->slice_outer_its;
+  // developer overrides, read once here (never inside a batch call)
+  if (const char *e = getenv("GIK_DBG")) t->dbg = atoi(e);
+  if (const char *e = getenv("GIK_WAVES_PER_CU")) t->wpc_override = std::max(1, atoi(e));
+  if (const char *e = getenv("GIK_SLICE")) t->slice_its = std::max(0, atoi(e));
   t->d_slot_meta = nullptr;
   t->d_counters = nullptr;
   t->next_counter = 0;
@@ -788,8 +809,7 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   }
   t->n_cu = prop.multiProcessorCount;
   t->waves_per_cu = std::max(1, std::min(occ, 32));
-  if (const char *e = getenv("GIK_DBG"))
-    if (atoi(e) & 32)
+  if (t->dbg & 32)
       fprintf(stderr, "gik_template_create: N=%d k=%d T=%d %s maxdeg=%d lds=%zu B occupancy=%d per CU, %d CUs\n",
               t->N, t->K, t->T, is_block ? "block" : "wave", is_block ? 0 : t->variant->maxdeg,
               t->smem_bytes, occ, t->n_cu);
@@ -854,7 +874,8 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   t->sweeps = d->jacobi_sweeps > 0 ? d->jacobi_sweeps : 10;
   t->prep_smem = sizeof(double) * ((size_t)5 * N * N + 2 * d->n_anchor + 96) + sizeof(int) * 48;
   // graphs beyond one wavefront's LDS: workgroup-per-goal kernel with its matrices in a global slab
-  t->prep_block = N > 32 || d->n_anchor > 32 || getenv("GIK_PREP_FORCE_BLOCK") != nullptr;  // (env: tests)
+  t->prep_block = N > 32 || d->n_anchor > 32 || d->force_block_prepare != 0 ||
+                  getenv("GIK_PREP_FORCE_BLOCK") != nullptr;
   if (t->prep_block) {
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prep_block_kernel, PREP_NT, 0) != hipSuccess)
@@ -1026,18 +1047,17 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   a.T = t->T;
   a.B = B;
   a.p = t->p;
-  {
-    const char *e = getenv("GIK_DBG");
-    a.dbg = e ? atoi(e) : 0;
-    a.dbg_buf = nullptr;
-    if (a.dbg & (4 | 8)) {
-      static double *buf = nullptr;
-      if (!buf) (void)hipMalloc((void **)&buf, 64 * 128 * 4 * sizeof(double));
-      (void)hipMemset(buf, 0, 64 * 128 * 4 * sizeof(double));
-      a.dbg_buf = buf;
-      g_dbg_buf = buf;
-    }
+  a.dbg = t->dbg;
+  a.dbg_buf = nullptr;
+#ifdef GIK_DEV
+  if (a.dbg & (4 | 8)) {
+    static double *buf = nullptr;
+    if (!buf) (void)hipMalloc((void **)&buf, 64 * 128 * 4 * sizeof(double));
+    (void)hipMemset(buf, 0, 64 * 128 * 4 * sizeof(double));
+    a.dbg_buf = buf;
+    g_dbg_buf = buf;
   }
+#endif
   gik_template *mt = const_cast<gik_template *>(t);  // the counter ring is the only mutable part
   a.work_counter = t->d_counters + (mt->next_counter.fetch_add(1) % kCounterRing);
   HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned int), (hipStream_t)stream));
@@ -1049,13 +1069,12 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   int wpc = t->waves_per_cu;
   // (planar problems are short and uniform: full occupancy is 7 % faster there)
   if (!t->is_block && t->K == 3 && wpc > 4 && (long long)B <= 12LL * 4 * t->n_cu) wpc = 4;
-  if (const char *e = getenv("GIK_WAVES_PER_CU")) wpc = std::max(1, atoi(e));  // developer override
+  if (t->wpc_override > 0) wpc = t->wpc_override;
   const int grid = std::min(B, t->n_cu * wpc);
   // Time slicing (workgroup-per-problem kernel): only when there are more problems than resident
-  // workgroups (otherwise everything starts at once anyway).  GIK_SLICE overrides the slice
-  // length, 0 disables.  Measured on UR10 + table, 4096 goals: 8.9 -> 7.7 s.
-  int slice = 256;
-  if (const char *e = getenv("GIK_SLICE")) slice = atoi(e);
+  // workgroups (otherwise everything starts at once anyway).  Slice length: the handle's
+  // slice_outer_its, 0 disables.  Measured on UR10 + table, 4096 goals: 8.9 -> 7.7 s.
+  int slice = t->slice_its;
   if (!t->is_block || B <= grid || (a.dbg & 1) || slice <= 0 || t->p.maxiter <= slice) slice = 0;
   a.slice_its = slice;
   a.q_tail = a.q_done = nullptr;
@@ -1110,6 +1129,7 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   return 0;
 }
 
+#ifdef GIK_DEV
 // developer hook (not part of the ABI header): cycles per iteration of one kernel component
 double gik_debug_parts(const gik_template *t, int mode, int iters) {
   using namespace gik;
@@ -1144,5 +1164,6 @@ int gik_debug_fetch(double *host, int n) {
   if (!gik::g_dbg_buf) return -1;
   return hipMemcpy(host, gik::g_dbg_buf, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
+#endif  // GIK_DEV
 
 }  // extern "C"

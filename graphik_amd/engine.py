@@ -55,6 +55,21 @@ def _dev(x, device):
     return t.contiguous()
 
 
+def _alloc_stats(B, device):
+    """[B] gik_stats records as a [B, sizeof(gik_stats) / 8] fp64 buffer."""
+    assert _ffi.STATS_BYTES % 8 == 0
+    return torch.zeros(B, _ffi.STATS_BYTES // 8, dtype=torch.float64, device=device)
+
+
+def _decode_stats(stats):
+    """Views of the gik_stats fields (layout taken from _ffi.Stats, i.e. from the header)."""
+    ints = stats.view(torch.int32)
+    out = {"f": stats[:, _ffi.STATS_F64["f"]], "gradnorm": stats[:, _ffi.STATS_F64["gradnorm"]]}
+    for name in ("iterations", "inner_total", "stop", "n_accept", "inner_executed"):
+        out[name] = ints[:, _ffi.STATS_I32[name]]
+    return out
+
+
 class Template:
     """Goal-independent part of an IK problem family, resident on one GPU."""
 
@@ -85,7 +100,8 @@ class Template:
         self.params = {f: getattr(d, f) for f in ("mingradnorm", "maxiter", "maxinner", "mininner",
                                                    "theta", "kappa", "rho_prime",
                                                    "rho_regularization", "planar_proj_exact",
-                                                   "force_block_path")}
+                                                   "force_block_path", "waves_per_cu",
+                                                   "slice_outer_its", "debug_flags")}
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _ffi.check(self.lib.gik_template_create(C.byref(d), C.byref(h)))
@@ -189,7 +205,8 @@ class Template:
     # -- device pre/post-processing ----------------------------------------------------------
     def attach_pipeline(self, *, T0, p_index, q_index, x_index, y_index, axis_length, goal_nodes,
                         goal_len, base_lower, base_upper, anchor_index, anchor_pos, pair_i, pair_j,
-                        term_src, term_static, last_link_along_z, jacobi_sweeps=0):
+                        term_src, term_static, last_link_along_z, jacobi_sweeps=0,
+                        force_block_prepare=False):
         """Give the handle what it needs to run from_pose + bound_smoothing +
         generate_initialization and joint_variables on the device (gik_pipeline_attach)."""
         keep = {}
@@ -221,6 +238,7 @@ class Template:
         d.term_static = arr("tv", term_static, np.float64)
         d.last_link_along_z = int(bool(last_link_along_z))
         d.jacobi_sweeps = int(jacobi_sweeps)
+        d.force_block_prepare = int(bool(force_block_prepare))
         with torch.cuda.device(self.device):
             _ffi.check(self.lib.gik_pipeline_attach(self._h, C.byref(d)))
         self.n_joints = int(d.n_joints)
@@ -269,16 +287,15 @@ class Template:
                                              out["Y"].data_ptr(), out["stats"].data_ptr(),
                                              out["q"].data_ptr(), out["pos_err"].data_ptr(),
                                              out["rot_err"].data_ptr(), self._stream()))
-        ints = out["stats"].view(torch.int32)
-        return {"x": out["Y"].reshape(B, self.N, self.k), "q": out["q"], "pos_err": out["pos_err"],
-                "rot_err": out["rot_err"], "f": out["stats"][:, 0], "gradnorm": out["stats"][:, 1],
-                "iterations": ints[:, 4], "inner_total": ints[:, 5], "stop": ints[:, 6],
-                "n_accept": ints[:, 7], "inner_executed": ints[:, 8]}
+        res = {"x": out["Y"].reshape(B, self.N, self.k), "q": out["q"], "pos_err": out["pos_err"],
+               "rot_err": out["rot_err"]}
+        res.update(_decode_stats(out["stats"]))
+        return res
 
     def alloc_ik_buffers(self, B):
         f64 = dict(dtype=torch.float64, device=self.device)
         return {"targets": torch.empty(B, self.T, **f64), "Y": torch.empty(B, self.N * self.k, **f64),
-                "stats": torch.zeros(B, 5, **f64), "q": torch.empty(B, self.n_joints, **f64),
+                "stats": _alloc_stats(B, self.device), "q": torch.empty(B, self.n_joints, **f64),
                 "pos_err": torch.empty(B, **f64), "rot_err": torch.empty(B, **f64)}
 
     # -- trust-region solve -------------------------------------------------------------------
@@ -288,7 +305,7 @@ class Template:
         Y, B = self._vec(Y_init)
         t = self._tg(targets, B)
         out = torch.empty_like(Y)
-        stats = torch.zeros(B, 5, dtype=torch.float64, device=self.device)  # gik_stats: 40 B / problem
+        stats = _alloc_stats(B, self.device)
         tr = None
         keep = {}
         if trace_cap > 0:
@@ -305,10 +322,8 @@ class Template:
                                                 out.data_ptr(), stats.data_ptr(),
                                                 C.byref(tr) if tr is not None else None,
                                                 self._stream()))
-        ints = stats.view(torch.int32)  # [B, 10]
-        res = {"x": out.reshape(B, self.N, self.k), "f": stats[:, 0], "gradnorm": stats[:, 1],
-               "iterations": ints[:, 4], "inner_total": ints[:, 5], "stop": ints[:, 6],
-               "n_accept": ints[:, 7], "inner_executed": ints[:, 8]}
+        res = {"x": out.reshape(B, self.N, self.k)}
+        res.update(_decode_stats(stats))
         if tr is not None:
             res["trace"] = keep
         return res

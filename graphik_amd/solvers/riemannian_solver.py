@@ -9,6 +9,8 @@ signatures and return shapes; `jit` / `use_jit` are accepted and ignored (there 
 implementation: the HIP kernels -- no CPU fallback).  `solve_batch` is the batched entry point
 the engine is built for.
 """
+import collections
+import hashlib
 import time
 
 import numpy as np
@@ -40,7 +42,7 @@ class RiemannianSolver:
                           "maxiter": int(params.get("maxiter", 3000)),
                           "theta": params.get("theta", 1.0), "kappa": params.get("kappa", 0.1)}
         for k in ("maxinner", "mininner", "rho_prime", "rho_regularization", "planar_proj_exact",
-                  "force_block_path"):
+                  "force_block_path", "waves_per_cu", "slice_outer_its", "debug_flags"):
             if k in params:
                 self.tr_params[k] = params[k]
         self.device = params.get("device", None)
@@ -127,7 +129,8 @@ class BatchProblem:
     """Goal-independent data of solve_with_riemannian for one problem graph, prepared once:
     edge template, which squared distances depend on the goal, anchors, limits."""
 
-    def __init__(self, graph, use_limits=True, params=None, device=None):
+    def __init__(self, graph, use_limits=True, params=None, device=None, force_block_prepare=False):
+        self.force_block_prepare = force_block_prepare
         self.graph = graph
         self.robot = graph.robot
         self.dim = graph.dim
@@ -202,7 +205,8 @@ class BatchProblem:
                           goal_nodes=self.goal_nodes, goal_len=goal_len, base_lower=lower,
                           base_upper=upper, anchor_index=self.anchor_nodes,
                           anchor_pos=self.anchor_pos, pair_i=I, pair_j=J, term_src=term_src,
-                          term_static=static, last_link_along_z=along_z)
+                          term_static=static, last_link_along_z=along_z,
+                          force_block_prepare=self.force_block_prepare)
         self.device_pipeline = True
 
     def goal_positions(self, T_goals):
@@ -281,15 +285,51 @@ class BatchProblem:
         return pos, rot
 
 
-_PROBLEM_CACHE = {}
+# BatchProblem objects (device handles) of recent solve_batch / solve_with_riemannian calls.  The
+# reference re-reads the graph on every call (riemannian_solver.py:220-234), so the key is the
+# CONTENT a BatchProblem is built from -- edge pattern, distances, limits, anchor positions, robot
+# frames -- not the identity of the graph object: a graph mutated in place (clear_obstacles +
+# add_spherical_obstacle, set_limits, ...) gets a fresh problem.  Least recently used entries are
+# dropped (their device handles are freed by Template.__del__).
+_PROBLEM_CACHE = collections.OrderedDict()
+_PROBLEM_CACHE_MAX = 8
+
+
+def graph_fingerprint(graph):
+    """Content hash of everything BatchProblem reads from a problem graph."""
+    h = hashlib.blake2b(digest_size=16)
+    h.update(repr((type(graph).__name__, graph.dim, graph.number_of_nodes(), tuple(graph.node_ids),
+                   float(getattr(graph, "axis_length", 0.0)))).encode())
+    for a in (graph.edge, graph.dist, graph.lower, graph.upper):
+        h.update(np.ascontiguousarray(a).tobytes())
+    if hasattr(graph, "bounded"):
+        h.update(repr(graph.bounded).encode() if not isinstance(graph.bounded, np.ndarray)
+                 else np.ascontiguousarray(graph.bounded).tobytes())
+    for name in graph.node_ids:
+        pos = graph.nodes[name].get(POS)
+        h.update(b"-" if pos is None else np.asarray(pos, dtype=float).tobytes())
+    h.update(np.ascontiguousarray(graph.robot.T0_array()).tobytes())
+    lb, ub = graph.robot.limits_arrays()
+    h.update(np.asarray(lb, dtype=float).tobytes() + np.asarray(ub, dtype=float).tobytes())
+    return h.hexdigest()
 
 
 def _problem_for(graph, use_limits=True, params=None, device=None):
-    key = (id(graph), graph.number_of_nodes(), use_limits, None if not params else tuple(sorted(params.items())),
-           device)
-    if key not in _PROBLEM_CACHE:
-        _PROBLEM_CACHE[key] = BatchProblem(graph, use_limits, params, device)
-    return _PROBLEM_CACHE[key]
+    key = (graph_fingerprint(graph), bool(use_limits),
+           None if not params else tuple(sorted(params.items())), None if device is None else str(device))
+    prob = _PROBLEM_CACHE.get(key)
+    if prob is None:
+        prob = _PROBLEM_CACHE[key] = BatchProblem(graph, use_limits, params, device)
+        while len(_PROBLEM_CACHE) > _PROBLEM_CACHE_MAX:
+            _PROBLEM_CACHE.popitem(last=False)
+    else:
+        _PROBLEM_CACHE.move_to_end(key)
+        prob.graph = graph      # same content, possibly another object: recover through the caller's
+    return prob
+
+
+def clear_problem_cache():
+    _PROBLEM_CACHE.clear()
 
 
 def solve_batch(graph, T_goals, use_limits=True, params=None, device=None, Y_init=None):

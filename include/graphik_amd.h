@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GIK_ABI_VERSION 2
+#define GIK_ABI_VERSION 3
 
 /* Residual-term kinds: one "term" per (index pair, kind) exactly as the loops of
  * costs.py:80-207 visit them: equality (omega != 0), lower hinge (psi_L != 0), upper hinge
@@ -67,6 +67,15 @@ typedef struct {
   double rho_regularization; /* 1e3                                                       */
   int32_t planar_proj_exact; /* 0: reproduce fixed_rank_psd_sym.py:107-110 literally (k=2) */
   int32_t force_block_path;  /* 1: use the workgroup-per-problem kernels even if N*k <= 64   */
+  /* scheduling knobs, fixed for the life of the handle (results never depend on them; the
+   * environment variables GIK_WAVES_PER_CU / GIK_SLICE / GIK_DBG are read ONCE, at
+   * gik_template_create, as developer overrides of these fields)                             */
+  int32_t waves_per_cu;      /* persistent solve waves (workgroups) per CU; 0 = automatic      */
+  int32_t slice_outer_its;   /* time slice of the workgroup-per-problem kernel in outer
+                                iterations; -1 = default (256), 0 = no time slicing            */
+  int32_t debug_flags;       /* developer flags (gik_solve.hip: SolveArgs::dbg); 16 = rerun tCG
+                                after a rejected step instead of resuming from the checkpoint  */
+  int32_t reserved0;
 } gik_template_desc;
 
 typedef struct gik_template gik_template; /* opaque handle, immutable after creation */
@@ -156,6 +165,9 @@ typedef struct {
   const double *term_static; /* [T] psi_L / psi_U / goal-independent squared distances     */
   int32_t last_link_along_z; /* the T_final correction of graph_revolute.py:314-316 applies */
   int32_t jacobi_sweeps;     /* 0 = default (10)                                           */
+  int32_t force_block_prepare; /* 1: workgroup-per-goal prepare kernel even for small graphs
+                                (tests; GIK_PREP_FORCE_BLOCK is read once, at attach)         */
+  int32_t reserved0;
 } gik_pipeline_desc;
 
 int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *desc);

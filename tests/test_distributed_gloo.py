@@ -49,3 +49,49 @@ def test_two_rank_gloo_gather(tmp_path):
     subprocess.run(cmd, check=True, env=env, timeout=300, capture_output=True)
     full = np.load(out)
     assert np.array_equal(full, np.arange(37.0)[:, None] * np.array([[1.0, 2.0, 3.0]]))
+
+
+def _bench_line(*extra):
+    """Run bench.py the way the driver does (`python bench.py --gpus N ...`, no launcher) and
+    return its one JSON line."""
+    import json
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--dry-solve", "--backend", "gloo",
+                        "--steps", "2", "--warmup", "1", *extra], env=env, timeout=600,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout        # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_ranks_and_gathers():
+    """`python bench.py --gpus 2` must bring up its two ranks itself (round 1 asserted on the world
+    size instead) and the table gathered from the two contiguous shards must be, row for row, the
+    single-process table -- through bench.py's own rank / shard / barrier / gather code, with a
+    deterministic stand-in for the device solve (--dry-solve)."""
+    one = _bench_line("--gpus", "1", "--config", "c4", "--batch", "0")
+    two = _bench_line("--gpus", "2", "--config", "c4")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["dry_solve"] and two["dry_solve"] and two["value"] is None
+    assert one["config"]["goals_total"] == two["config"]["goals_total"] == 65536    # strong scaling
+    assert one["rows"] == two["rows"] == 65536
+    assert one["rows_sha"] == two["rows_sha"]
+    assert two["scaling"] == "strong"
+    # weak-scaling default (BASELINE configs[1]): every rank brings its own 4096 goals
+    w2 = _bench_line("--gpus", "2")
+    assert w2["config"]["robot"] == "lwa4d" and w2["rows"] == 2 * 4096 and w2["scaling"] == "weak"
+    # c5 shards the planar chain the same way (uneven world sizes included)
+    p1, p3 = _bench_line("--gpus", "1", "--config", "c5"), _bench_line("--gpus", "3", "--config", "c5")
+    assert p1["rows_sha"] == p3["rows_sha"] and p3["rows"] == 65536
+
+
+def test_bench_refuses_a_wrong_world_size():
+    """Started under a launcher whose world size is not --gpus, bench.py must say so (not assert)."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--dry-solve", "--gpus", "2"],
+                       env=env, timeout=300, capture_output=True, text=True)
+    assert r.returncode != 0 and "launcher started 1 rank" in (r.stderr + r.stdout)

@@ -300,7 +300,7 @@ def test_checkpoint_resume_is_bit_identical(torch_cuda, monkeypatch, name):
     """After a rejected step the reference's next tCG solve repeats the previous one up to the
     smaller radius; the engine resumes from a checkpoint instead.  Same arithmetic, so the results
     (points, costs, every counter the reference would report, the per-iteration trace) must equal
-    those of actually rerunning tCG (GIK_DBG=16), bit for bit; only the executed work differs."""
+    those of actually rerunning tCG (debug_flags = 16), bit for bit; only the executed work differs."""
     from graphik_amd.solvers.riemannian_solver import BatchProblem
     from graphik_amd.engine import Template
     block = name.endswith("_block")          # the workgroup-per-problem kernel keeps its checkpoint too
@@ -309,20 +309,19 @@ def test_checkpoint_resume_is_bit_identical(torch_cuda, monkeypatch, name):
     rng = np.random.RandomState(21)
     Tg = robot.fk_batch(-np.pi + 2 * np.pi * rng.rand(96 if block else 384, robot.n))
     targets, Y0 = prob.prepare(Tg)
-    tpl = prob.template if not block else Template.from_matrices(
-        prob.omega, prob.psi_L, prob.psi_U, k=3, use_limits=True, params={"force_block_path": 1})
+    def template(debug_flags):
+        return Template.from_matrices(prob.omega, prob.psi_L, prob.psi_U, k=3, use_limits=True,
+                                      params={"force_block_path": int(block), "debug_flags": debug_flags})
 
-    def run():
-        r = tpl.solve(Y0, targets, trace_cap=96)
+    def run(debug_flags=0):
+        r = template(debug_flags).solve(Y0, targets, trace_cap=96)
         out = {k: r[k].cpu().numpy() for k in ("x", "f", "gradnorm", "iterations", "inner_total",
                                               "stop", "n_accept", "inner_executed")}
         out.update({"t_" + k: v.cpu().numpy() for k, v in r["trace"].items()})
         return out
 
     a = run()
-    monkeypatch.setenv("GIK_DBG", "16")
-    b = run()
-    monkeypatch.delenv("GIK_DBG")
+    b = run(debug_flags=16)
     for k in a:
         if k != "inner_executed":
             assert np.array_equal(a[k], b[k], equal_nan=True), k
@@ -333,7 +332,7 @@ def test_checkpoint_resume_is_bit_identical(torch_cuda, monkeypatch, name):
 
 def test_time_slicing_is_bit_identical(torch_cuda, monkeypatch):
     """The workgroup-per-problem kernel re-queues a problem that has not met a stopping rule after
-    GIK_SLICE outer iterations (default 256) behind everything that is waiting, so that the long
+    slice_outer_its outer iterations (default 256) behind everything that is waiting, so that the long
     problems of a batch do not start last.  A solve is exactly resumable from (x, Delta,
     counters), so the results must not depend on the slice length; only the executed work may (the
     tCG checkpoint is dropped at a slice boundary)."""
@@ -344,16 +343,14 @@ def test_time_slicing_is_bit_identical(torch_cuda, monkeypatch):
     rng = np.random.RandomState(12)
     Tg = robot.fk_batch(-np.pi + 2 * np.pi * rng.rand(600, robot.n))     # more problems than workgroups
     targets, Y0 = prob.prepare(Tg)
-    tpl = Template.from_matrices(prob.omega, prob.psi_L, prob.psi_U, k=3, use_limits=True,
-                                 params={"force_block_path": 1})
     keys = ("x", "f", "gradnorm", "iterations", "inner_total", "stop", "n_accept")
     runs = {}
     for sl in ("0", "256", "24"):
-        monkeypatch.setenv("GIK_SLICE", sl)
+        tpl = Template.from_matrices(prob.omega, prob.psi_L, prob.psi_U, k=3, use_limits=True,
+                                     params={"force_block_path": 1, "slice_outer_its": int(sl)})
         r = tpl.solve(Y0, targets, trace_cap=40)
         runs[sl] = {k: r[k].cpu().numpy() for k in keys + ("inner_executed",)}
         runs[sl]["numit"] = r["trace"]["numit"].cpu().numpy()
-    monkeypatch.delenv("GIK_SLICE")
     assert (runs["0"]["iterations"] > 256).sum() > 20          # problems that do get re-queued
     for sl in ("256", "24"):
         for k in keys + ("numit",):
@@ -366,16 +363,14 @@ def test_results_independent_of_persistent_grid(torch_cuda, monkeypatch):
     waves is a scheduling choice (one or two per SIMD, gik_solve_batch) and must not change a
     single bit of any result."""
     d = load_golden("lwa4d")
-    T = _template(d, maxiter=60)
     reps = 40
     Y0 = np.tile(d["Y_init"], (reps, 1, 1))
-    tg = np.tile(T.targets_from_D(d["D_goal"]), (reps, 1))
     outs = []
-    for wpc in ("1", "4", "8"):
-        monkeypatch.setenv("GIK_WAVES_PER_CU", wpc)
+    for wpc in (1, 4, 8):
+        T = _template(d, maxiter=60, waves_per_cu=wpc)
+        tg = np.tile(T.targets_from_D(d["D_goal"]), (reps, 1))
         r = T.solve(Y0, tg)
         outs.append((r["x"].cpu().numpy(), r["iterations"].cpu().numpy(), r["inner_total"].cpu().numpy()))
-    monkeypatch.delenv("GIK_WAVES_PER_CU")
     for o in outs[1:]:
         assert all(np.array_equal(a, b) for a, b in zip(outs[0], o))
     # and every replica of a goal gives the same answer
@@ -494,12 +489,9 @@ def test_block_prepare_kernel_equals_wave_kernel(torch_cuda, monkeypatch, name):
     Tg = robot.fk_batch(lb_q + (ub_q - lb_q) * rng.rand(700, robot.n))    # more goals than workgroups
     out = []
     for force in (False, True):
-        if force:
-            monkeypatch.setenv("GIK_PREP_FORCE_BLOCK", "1")
-        prob = BatchProblem(graph, use_limits=True)
+        prob = BatchProblem(graph, use_limits=True, force_block_prepare=force)
         tg, Y, K = prob.template.prepare(Tg, return_K=True)
         out.append((tg.cpu().numpy(), Y.cpu().numpy(), K.cpu().numpy()))
-    monkeypatch.delenv("GIK_PREP_FORCE_BLOCK")
     for a, b in zip(*out):
         assert np.array_equal(a, b)
 

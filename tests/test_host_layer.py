@@ -185,3 +185,29 @@ def test_bench_algorithmic_work_matches_survey():
     assert bench.algorithmic_flops(18, 3, 75, 1, 0, 0) == 4383
     assert bench.algorithmic_flops(13, 2, 19, 1, 0, 0) == 1116      # planar chain, C5
     assert bench.algorithmic_bytes(18, 3, 75) == 8 * (75 + 2 * 54) + 32
+
+
+def test_problem_cache_key_follows_graph_content():
+    """solve_batch caches device problems by the CONTENT of the graph (the reference re-reads the
+    graph on every call): in-place mutations that keep the node count -- moving an obstacle,
+    intended obstacle semantics, other joint limits -- must change the key; an equal graph built
+    separately must not."""
+    from graphik_amd.solvers.riemannian_solver import graph_fingerprint
+    from graphik_amd.utils.roboturdf import load_ur10
+    _, g = load_ur10()
+    _, g_same = load_ur10()
+    base = graph_fingerprint(g)
+    assert base == graph_fingerprint(g_same)
+    g.add_spherical_obstacle("o0", np.array([0.5, 0.1, 0.3]), 0.1)
+    one = graph_fingerprint(g)
+    assert one != base
+    g.clear_obstacles()
+    assert graph_fingerprint(g) == base
+    g.add_spherical_obstacle("o0", np.array([0.5, 0.1, 0.4]), 0.1)       # same count, elsewhere
+    moved = graph_fingerprint(g)
+    assert moved != one
+    g.clear_obstacles()
+    g.add_spherical_obstacle("o0", np.array([0.5, 0.1, 0.3]), 0.1, intended=True)
+    assert graph_fingerprint(g) not in (one, moved)
+    _, g_lim = load_ur10(limits=(-np.pi / 2 * np.ones(6), np.pi / 2 * np.ones(6)))
+    assert graph_fingerprint(g_lim) != base
