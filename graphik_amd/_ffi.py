@@ -67,6 +67,10 @@ class PipelineDesc(C.Structure):
     ]
 
 
+class PrepareDiag(C.Structure):
+    _fields_ = [("d_lb", C.c_void_p), ("d_ub", C.c_void_p), ("d_eig", C.c_void_p)]
+
+
 # every symbol include/graphik_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "gik_last_error": (C.c_char_p, []),
@@ -87,6 +91,8 @@ SYMBOLS = {
     "gik_pipeline_attach": (C.c_int, [C.c_void_p, C.POINTER(PipelineDesc)]),
     "gik_prepare_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
+    "gik_prepare_batch_debug": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.POINTER(PrepareDiag), C.c_void_p]),
     "gik_recover_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "gik_ik_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,

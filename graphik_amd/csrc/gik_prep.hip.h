@@ -160,6 +160,10 @@ struct PrepArgs {
   double *targets;       // [B][T]
   double *Y_init;        // [B][N*K]
   int *K_out;            // [B] MDS column count (diagnostic), may be null
+  // diagnostics (gik_prepare_batch_debug), each may be null: bound_smoothing's output and the three
+  // eigenvalue spectra of generate_initialization (Gram matrix, MDS's rank matrix, scatter matrix)
+  double *dbg_lb, *dbg_ub;  // [B][N*N]
+  double *dbg_eig;          // [B][3][N]
   int B, sweeps;
 };
 
@@ -239,6 +243,11 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
       V[e] = best;
     }
     __builtin_amdgcn_wave_barrier();
+    if (a.dbg_lb)
+      for (int e = lane; e < NN; e += WAVE) {
+        a.dbg_lb[(size_t)b * NN + e] = V[e];
+        a.dbg_ub[(size_t)b * NN + e] = U[e];
+      }
     // ---- generate_initialization: D_rand = (lb + 0.9 (ub - lb))^2, Gram = -1/2 J D J
     for (int e = lane; e < NN; e += WAVE) {
       const double lbv = V[e], d = lbv + 0.9 * (U[e] - lbv);
@@ -263,6 +272,7 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
     jacobi_lds(A, V, N, a.sweeps, cs, pq, lane);
     // ---- factor(): clip, scale by sqrt(lambda), order descending (fliplr of ascending)
     if (lane < N) ev[lane] = A[lane * N + lane];
+    if (a.dbg_eig && lane < N) a.dbg_eig[((size_t)b * 3 + 0) * N + lane] = A[lane * N + lane];
     __builtin_amdgcn_wave_barrier();
     if (lane < N) {
       rk[lane] = desc_rank(ev, N, lane);
@@ -295,6 +305,7 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
     int Kc = 0;
     for (int j = 0; j < N; ++j) Kc += A[j * N + j] > 1e-8;
     if (a.K_out && lane == 0) a.K_out[b] = Kc;
+    if (a.dbg_eig && lane < N) a.dbg_eig[((size_t)b * 3 + 1) * N + lane] = A[lane * N + lane];
     __builtin_amdgcn_wave_barrier();
     // ---- linear_projection (dgp.py:174-183): scatter of the edge differences of the first Kc
     //      columns, its top-`dim` eigenvectors
@@ -318,6 +329,7 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
     __builtin_amdgcn_wave_barrier();
     jacobi_lds(A, V, N, a.sweeps, cs, pq, lane, Kc > 1 ? Kc : 2);
     if (lane < N) ev[lane] = (lane < Kc) ? A[lane * N + lane] : -INFINITY;
+    if (a.dbg_eig && lane < N) a.dbg_eig[((size_t)b * 3 + 2) * N + lane] = (lane < Kc) ? A[lane * N + lane] : 0.0;
     __builtin_amdgcn_wave_barrier();
     if (lane < N) {
       rk[lane] = desc_rank(ev, N, lane);
@@ -514,6 +526,11 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       V[e] = best;
     }
     __syncthreads();
+    if (a.dbg_lb)
+      for (int e = tid; e < NN; e += PREP_NT) {
+        a.dbg_lb[(size_t)b * NN + e] = V[e];
+        a.dbg_ub[(size_t)b * NN + e] = U[e];
+      }
     // ---- generate_initialization: D_rand = (lb + 0.9 (ub - lb))^2, Gram = -1/2 J D J
     for (int e = tid; e < NN; e += PREP_NT) {
       const double lbv = V[e], d = lbv + 0.9 * (U[e] - lbv);
@@ -539,6 +556,7 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
     // ---- factor(): clip, scale by sqrt(lambda), order descending
     __syncthreads();
     if (tid < N) ev[tid] = A[tid * N + tid];
+    if (a.dbg_eig && tid < N) a.dbg_eig[((size_t)b * 3 + 0) * N + tid] = A[tid * N + tid];
     __syncthreads();
     if (tid < N) {
       rk[tid] = desc_rank(ev, N, tid);
@@ -569,6 +587,7 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
     int Kc = 0;
     for (int j = 0; j < N; ++j) Kc += A[j * N + j] > 1e-8;
     if (a.K_out && tid == 0) a.K_out[b] = Kc;
+    if (a.dbg_eig && tid < N) a.dbg_eig[((size_t)b * 3 + 1) * N + tid] = A[tid * N + tid];
     __syncthreads();
     // ---- linear_projection (dgp.py:174-183)
     for (int e = tid; e < NN; e += PREP_NT) {
@@ -617,6 +636,7 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
     jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid, Kc > 1 ? Kc : 2);
     __syncthreads();
     if (tid < N) ev[tid] = (tid < Kc) ? A[tid * N + tid] : -INFINITY;
+    if (a.dbg_eig && tid < N) a.dbg_eig[((size_t)b * 3 + 2) * N + tid] = (tid < Kc) ? A[tid * N + tid] : 0.0;
     __syncthreads();
     if (tid < N) {
       rk[tid] = desc_rank(ev, N, tid);

@@ -906,6 +906,12 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
 
 int gik_prepare_batch(const gik_template *t, const double *d_T_goal, int B, double *d_targets,
                       double *d_Y_init, int32_t *d_K_out, void *stream) {
+  return gik_prepare_batch_debug(t, d_T_goal, B, d_targets, d_Y_init, d_K_out, nullptr, stream);
+}
+
+int gik_prepare_batch_debug(const gik_template *t, const double *d_T_goal, int B, double *d_targets,
+                            double *d_Y_init, int32_t *d_K_out, const gik_prepare_diag *diag,
+                            void *stream) {
   using namespace gik;
   if (!t || B < 0) return fail("bad argument");
   if (!t->has_pipe) return fail("no pipeline attached (gik_pipeline_attach)");
@@ -917,6 +923,10 @@ int gik_prepare_batch(const gik_template *t, const double *d_T_goal, int B, doub
   a.targets = d_targets;
   a.Y_init = d_Y_init;
   a.K_out = d_K_out;
+  a.dbg_lb = diag ? diag->d_lb : nullptr;
+  a.dbg_ub = diag ? diag->d_ub : nullptr;
+  a.dbg_eig = diag ? diag->d_eig : nullptr;
+  if ((a.dbg_lb == nullptr) != (a.dbg_ub == nullptr)) return fail("d_lb and d_ub go together");
   a.B = B;
   a.sweeps = t->sweeps;
   const int grid = std::min(B, t->n_cu * t->prep_waves_per_cu);

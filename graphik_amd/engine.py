@@ -263,6 +263,24 @@ class Template:
         Y0 = Y0.reshape(B, self.N, self.k)
         return (targets, Y0, Kc) if return_K else (targets, Y0)
 
+    def prepare_debug(self, T_goal):
+        """prepare() plus the intermediate results the reference computes on the way: dict with
+        targets, Y_init, K (MDS column count), lb, ub [B,N,N] (bound_smoothing) and eig [B,3,N]
+        (spectra of the Gram matrix, of MDS's rank matrix and of the scatter matrix)."""
+        T, B = self._poses(T_goal)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        out = {"targets": torch.empty(B, self.T, **f64), "Y_init": torch.empty(B, self.N * self.k, **f64),
+               "K": torch.zeros(B, dtype=torch.int32, device=self.device),
+               "lb": torch.empty(B, self.N, self.N, **f64), "ub": torch.empty(B, self.N, self.N, **f64),
+               "eig": torch.empty(B, 3, self.N, **f64)}
+        dg = _ffi.PrepareDiag(out["lb"].data_ptr(), out["ub"].data_ptr(), out["eig"].data_ptr())
+        with torch.cuda.device(self.device):
+            _ffi.check(self.lib.gik_prepare_batch_debug(self._h, T.data_ptr(), B, out["targets"].data_ptr(),
+                                                        out["Y_init"].data_ptr(), out["K"].data_ptr(),
+                                                        C.byref(dg), self._stream()))
+        out["Y_init"] = out["Y_init"].reshape(B, self.N, self.k)
+        return out
+
     def recover(self, Y, T_goal):
         """points + goal poses -> (q [B,n], pos_err [B], rot_err [B]) on the device."""
         Y, B = self._vec(Y)

@@ -142,13 +142,14 @@ def _canonical_signs(V):
     return V * np.where(sgn == 0, 1.0, sgn)
 
 
-def generate_initialization_batch(lb, ub, dim, omega, canonical=False):
+def generate_initialization_batch(lb, ub, dim, omega, canonical=False, return_info=False):
     """Vectorised generate_initialization: lb, ub [B,N,N] -> Y_init [B,N,dim].
 
     canonical=False keeps LAPACK's eigenvector signs (what the reference gets).  The column count
     K of MDS() is the number of positive eigenvalues of a matrix built from the LOWER TRIANGLE of
     the eigenvector factor, so it depends on those arbitrary signs; canonical=True fixes them by
-    a rule (largest-magnitude entry positive), which is what the device kernel implements."""
+    a rule (largest-magnitude entry positive), which is what the device kernel implements.
+    return_info=True also returns {"K", "ev_gram" (ascending), "ev_rank" (ascending)}."""
     B, N, _ = lb.shape
     D = (lb + 0.9 * (ub - lb)) ** 2
     G = gram_from_distance_matrix(D)
@@ -176,4 +177,7 @@ def generate_initialization_batch(lb, ub, dim, omega, canonical=False):
     _, W = np.linalg.eigh(S)
     if canonical:
         W = _canonical_signs(W)
-    return X @ W[:, :, ::-1][:, :, :dim]
+    Y = X @ W[:, :, ::-1][:, :, :dim]
+    if return_info:
+        return Y, {"K": K, "ev_gram": ev, "ev_rank": ev2}
+    return Y

@@ -178,6 +178,20 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *desc);
 int gik_prepare_batch(const gik_template *t, const double *d_T_goal, int B, double *d_targets,
                       double *d_Y_init, int32_t *d_K_out, void *stream);
 
+/* Diagnostic twin of gik_prepare_batch: also returns what the reference computes on the way, so
+ * that each stage can be checked against captured reference data on its own -- bound_smoothing's
+ * output (dgp.py:192-231) and the eigenvalue spectra behind generate_initialization
+ * (riemannian_solver.py:67-75; dgp.py:150-183): row 0 the Gram matrix of the interpolated bounds,
+ * row 1 the matrix MDS() takes its rank from (dgp.py:166-167), row 2 the scatter matrix of
+ * linear_projection (zero beyond the MDS rank); all unsorted.  Any pointer may be NULL.        */
+typedef struct {
+  double *d_lb, *d_ub;   /* [B][N*N]  (both or neither)                                       */
+  double *d_eig;         /* [B][3][N]                                                         */
+} gik_prepare_diag;
+int gik_prepare_batch_debug(const gik_template *t, const double *d_T_goal, int B,
+                            double *d_targets, double *d_Y_init, int32_t *d_K_out,
+                            const gik_prepare_diag *diag, void *stream);
+
 /* points [B][N*k] + goal poses -> joint angles [B][n], EE position / rotation error of
  * FK(q) against the goal [B] (joint_variables + robot.pose + the examples' error metric).  */
 int gik_recover_batch(const gik_template *t, const double *d_Y, const double *d_T_goal, int B,

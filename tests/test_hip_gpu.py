@@ -137,50 +137,110 @@ def test_trajectory_planar_identical_to_oracle(torch_cuda, name):
     assert exact_tail >= len(d["seed"]) // 2
 
 
-@pytest.mark.parametrize("name", SCENARIOS_3D)
-def test_trajectory_prefix_3d(torch_cuda, name):
-    """3-D: identical discrete decisions for the first 5 outer iterations, f and |grad| to 1e-6
-    (the reference's two own code paths diverge after 7-40 iterations, tests/test_oracle_golden)."""
-    from oracle import c_oracle as co
-    d = load_golden(name)
-    T = _template(d)
+def _hip_traces(d, path):
+    from graphik_amd.engine import Template
+    T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=3, use_limits=True,
+                               params={"force_block_path": int(path == "block")})
     r = T.solve(d["Y_init"], T.targets_from_D(d["D_goal"]), trace_cap=48)
     tr = {k: v.cpu().numpy() for k, v in r["trace"].items()}
+    return r, [{k: tr[k][g] for k in tr} for g in range(len(d["seed"]))]
+
+
+@pytest.mark.parametrize("path", ["wave", "block"])
+@pytest.mark.parametrize("name", SCENARIOS_3D)
+def test_trajectory_prefix_3d(torch_cuda, name, path):
+    """identical discrete decisions and f, |grad| to 1e-8 for the outer iterations
+    k <= 20 -- on both kernel paths, for every robot.  3-D solves amplify round-off (~10x every few
+    outer iterations), so each golden goal is pinned as far as the REFERENCE reproduces itself:
+      (1) strictly -- decisions identical, f / |grad| to 1e-8 against the oracle -- up to
+          min(20, K12), K12 = first iteration at which the reference's numpy path (fixture) and the
+          oracle (the costs.py loops restated) differ by more than 1e-12, i.e. while they are still
+          the same computation; never fewer than 5 iterations;
+      (2) in distribution: the HIP trajectory leaves the oracle's (1e-8) no earlier than the
+          reference's own numpy path does, for at least 2/3 of the goals, and the summed prefix
+          lengths (capped at 20) reach 85 % of the reference pair's."""
+    from oracle import c_oracle as co
+    from parity_util import (CONTRACT_K, assert_prefix_equal, first_divergence, golden_traj, report,
+                             stable_prefix)
+    d = load_golden(name)
+    r, traces = _hip_traces(d, path)
+    its = r["iterations"].cpu().numpy()
+    n_np = d["np_traj_numit"].shape[0]
+    k_hip, k_ref, pinned = [], [], []
     for g in range(len(d["seed"])):
         o = co.rtr_solve(d["Y_init"][g], d["D_goal"][g], d["omega"], d["psi_L"], d["psi_U"], True,
-                         traj_cap=8)
+                         traj_cap=48)
+        n = min(48, int(its[g]), o["iterations"])
         m = 5
-        assert np.array_equal(tr["numit"][g][:m], o["traj"]["numit"][:m])
-        assert np.array_equal(tr["stop"][g][:m], o["traj"]["stop"][:m])
-        assert np.array_equal(tr["accept"][g][:m], o["traj"]["accept"][:m])
-        assert np.array_equal(tr["Delta"][g][:m], o["traj"]["Delta"][:m])
-        assert np.allclose(tr["f_before"][g][:m], o["traj"]["f_before"][:m], rtol=1e-6)
-        assert np.allclose(tr["gradnorm_after"][g][:m], o["traj"]["gradnorm_after"][:m], rtol=1e-6)
-        assert np.array_equal(tr["numit"][g][:m], d["np_traj_numit"][g][:m]) if g < d["np_traj_numit"].shape[0] else True
+        if g < n_np:
+            ref = golden_traj(d, "np", g)
+            n = min(n, int(d["iterations"][g]))
+            m = max(5, min(CONTRACT_K, stable_prefix(o["traj"], ref, n)))
+            k_ref.append(min(CONTRACT_K, first_divergence(o["traj"], ref, n)))
+            k_hip.append(min(CONTRACT_K, first_divergence(traces[g], o["traj"], n)))
+            assert np.array_equal(traces[g]["numit"][:m], ref["numit"][:m])      # the reference itself
+        assert_prefix_equal(traces[g], o["traj"], m)
+        pinned.append(m)
+    k_hip, k_ref = np.array(k_hip), np.array(k_ref)
+    report(f"trajectory_prefix/{name}/{path}", {
+        "strictly_pinned_iterations": pinned, "hip_leaves_oracle_at": k_hip.tolist(),
+        "reference_np_leaves_oracle_at": k_ref.tolist()})
+    assert np.mean(k_hip >= k_ref) >= 2.0 / 3.0, (k_hip, k_ref)
+    assert k_hip.sum() >= 0.85 * k_ref.sum(), (k_hip, k_ref)
 
 
+@pytest.mark.parametrize("path", ["wave", "block"])
 @pytest.mark.parametrize("name", SCENARIOS_3D)
-def test_finals_statistical_3d(torch_cuda, name):
-    """End-to-end parity is statistical: same convergence class per goal, same
-    order of iteration counts, EE errors in the reference's band."""
+def test_finals_statistical_3d(torch_cuda, name, path):
+    """End-to-end parity of the recovered joint configurations (same IK branch,
+    max |dq| < 1e-3 rad after wrapping).  Pointwise that bar only exists where the reference meets
+    it against itself: its own two code paths (numpy closures vs costs.py loops, fixtures) end
+    1e-2 rad apart on the 7-DOF arms, whose solution sets are self-motion curves.  So:
+      * on every goal where the reference's two paths agree to 1e-3, HIP agrees with it to 1e-3;
+      * UR10 (6 DOF, isolated solutions): every converged goal to 1e-3 (block path: 90 % to 1e-3,
+        all to 5e-3 -- one slowly converging goal, f = 1e-13, sits at 1.3e-3);
+      * the 7-DOF arms in distribution: median |dq| against the reference no larger than 3x the
+        oracle's own median |dq| against it (or than the reference's two paths are apart), and
+        nothing beyond the self-motion scale (0.2 rad) except where the oracle leaves the
+        reference's branch as well;
+      * convergence class per goal, iteration counts and EE errors as before.
+    The measured distributions are written to gpurun_out/parity_report.json."""
+    from oracle import c_oracle as co
+    from parity_util import report, wrap_abs
+    from graphik_amd.graphs.graph_revolute import joint_variables_revolute_batch
     d = load_golden(name)
     robot, graph = make_graph(name)
-    T = _template(d)
-    r = T.solve(d["Y_init"], T.targets_from_D(d["D_goal"]))
+    r, _ = _hip_traces(d, path)
     f = r["f"].cpu().numpy()
     its = r["iterations"].cpu().numpy()
     assert np.array_equal(f < 1e-9, d["f_sol"] < 1e-9)
     assert 0.5 < np.median(its) / np.median(d["iterations"]) < 2.0
-    from graphik_amd.graphs.graph_revolute import joint_variables_revolute_batch
     q = joint_variables_revolute_batch(graph, r["x"].cpu().numpy(), d["T_goal"])
     Ts = robot.fk_batch(q)
     pos = np.linalg.norm(Ts[:, :3, 3] - d["T_goal"][:, :3, 3], axis=1)
     conv = d["f_sol"] < 1e-9
     assert np.median(pos[conv]) < 3 * np.median(d["pos_err"][conv]) + 1e-6
     assert np.all(pos[conv] < 5e-3)
-    # same IK branch as the reference wherever the reference itself is reproducible
-    dq = np.abs(np.mod(q - d["q_sol"] + np.pi, 2 * np.pi) - np.pi).max(axis=1)
-    assert np.mean(dq[conv] < 5e-2) > 0.7
+    dq = wrap_abs(q - d["q_sol"]).max(axis=1)
+    o = co.rtr_solve_batch(d["Y_init"], d["D_goal"], d["omega"], d["psi_L"], d["psi_U"], True, fast=False)
+    dq_orc = wrap_abs(joint_variables_revolute_batch(graph, o["x"], d["T_goal"]) - d["q_sol"]).max(axis=1)
+    nl = d["loop_q_sol"].shape[0]
+    dq_ref = wrap_abs(d["q_sol"][:nl] - d["loop_q_sol"]).max(axis=1)
+    report(f"finals_dq/{name}/{path}", {
+        "reference_np_vs_loops": dq_ref.tolist(), "hip_vs_reference_np": dq.tolist(),
+        "oracle_vs_reference_np": dq_orc.tolist(), "converged": conv.astype(int).tolist(),
+        "iterations_hip": its.tolist(), "iterations_reference": d["iterations"].tolist()})
+    for g in range(nl):
+        if dq_ref[g] < 1e-3:
+            assert dq[g] < 1e-3, (g, dq[g], dq_ref[g])
+    if robot.n == 6:
+        if path == "wave":
+            assert np.all(dq[conv] < 1e-3), dq
+        else:
+            assert np.mean(dq[conv] < 1e-3) >= 0.9 and np.all(dq[conv] < 5e-3), dq
+    else:
+        assert np.median(dq[conv]) <= max(3 * np.median(dq_orc[conv]), dq_ref.max()) + 1e-4, (dq, dq_orc)
+        assert np.all((dq[conv] < 0.2) | (dq_orc[conv] > 0.05)), (dq, dq_orc)
 
 
 @pytest.mark.parametrize("name", SCENARIOS_3D)
@@ -463,18 +523,127 @@ def test_device_prepare_matches_host(torch_cuda, name):
     tg_h = prob.template.targets_from_D(D)
     assert np.abs(tg_d - tg_h).max() <= 1e-12 * np.abs(tg_h).max()
     lb, ub = dgp.floyd_warshall_bounds(lo, up)
-    Y_h = dgp.generate_initialization_batch(lb, ub, graph.dim, prob.omega, canonical=True)
+    Y_h, info_h = dgp.generate_initialization_batch(lb, ub, graph.dim, prob.omega, canonical=True,
+                                                    return_info=True)
+    cls = _classify_init(Y_d, K_d, Y_h, info_h)
+    assert cls["unexplained"] == 0, cls
+    assert cls["identical"] >= 0.97 * len(Tg), cls
+    ok = cls["mask_identical"]
+    assert np.abs(np.abs(Y_d[ok]) - np.abs(Y_h[ok])).max() < 1e-7
+    assert np.all(K_d >= graph.dim) and np.all(K_d <= graph.number_of_nodes())
+
+
+def _classify_init(Y_d, K_d, Y_h, info_h, tol=1e-8):
+    """Every goal's device initial point against a host rendering of generate_initialization:
+    identical (Gram matrices equal to 1e-8 -- Y_init is defined up to the signs of its columns),
+    or explained by a DIFFERENT MDS column count K whose cause is visible in the data -- an
+    eigenvalue of the rank matrix within a factor 4 of MDS's 1e-8 threshold ("near_threshold"), or,
+    when comparing with the reference's LAPACK-sign rendering, the sign dependence of that matrix
+    ("sign_rule": K differs although no eigenvalue is near the threshold) -- or unexplained."""
+    B = len(Y_d)
     G_d = Y_d @ np.swapaxes(Y_d, 1, 2)
     G_h = Y_h @ np.swapaxes(Y_h, 1, 2)
-    err = np.abs(G_d - G_h).reshape(len(Tg), -1).max(axis=1) / np.abs(G_h).reshape(len(Tg), -1).max(axis=1)
-    assert np.mean(err < 1e-8) > 0.9, np.sort(err)[-10:]
-    assert np.abs(np.abs(Y_d[err < 1e-8]) - np.abs(Y_h[err < 1e-8])).max() < 1e-7
-    # the reference's own initial points (LAPACK signs) coincide whenever the rank rule agrees
-    Y_ref = dgp.generate_initialization_batch(lb, ub, graph.dim, prob.omega, canonical=False)
-    G_r = Y_ref @ np.swapaxes(Y_ref, 1, 2)
-    same = np.abs(G_d - G_r).reshape(len(Tg), -1).max(axis=1) < 1e-8 * np.abs(G_r).max()
-    assert same.mean() > 0.25
-    assert np.all(K_d >= graph.dim) and np.all(K_d <= graph.number_of_nodes())
+    err = np.abs(G_d - G_h).reshape(B, -1).max(axis=1) / np.abs(G_h).reshape(B, -1).max(axis=1)
+    same = err < tol
+    near = np.any((info_h["ev_rank"] > 0.25e-8) & (info_h["ev_rank"] < 4e-8), axis=1)
+    kdiff = K_d != info_h["K"]
+    out = {"goals": B, "identical": int(same.sum()),
+           "near_threshold": int((~same & near).sum()),
+           "sign_rule": int((~same & ~near & kdiff).sum()),
+           "unexplained": int((~same & ~near & ~kdiff).sum()),
+           "K_differs": int(kdiff.sum()), "max_err_identical": float(err[same].max()) if same.any() else 0.0}
+    out["mask_identical"] = same
+    return out
+
+
+@pytest.mark.parametrize("name", ["lwa4d", "ur10", "kuka", "planar10_nolimits", "planar10_limits_pi",
+                                  "planar10_limits_halfpi", "ur10_table"])
+def test_device_prepare_against_reference_fixtures(torch_cuda, name):
+    """a10 / a11 against data captured from the reference itself (tests/golden, one hop):
+      * bound_smoothing (dgp.py:192-231): device lb, ub == the reference's networkx output, 1e-12;
+      * the Gram matrix's spectrum == eigvalsh of the Gram built from the reference's lb, ub, 1e-10;
+      * generate_initialization (riemannian_solver.py:67-75): Gram(device Y_init) == Gram(reference
+        Y_init) for EVERY goal whose MDS column count K equals the reference's.  K is the one thing
+        that cannot be pinned: dgp.py:166-167 takes it from eigh() of the non-symmetric eigenvector
+        factor (its lower triangle), which depends on the signs LAPACK happens to return.  Each goal
+        is classified (identical / K differs by the sign rule / eigenvalue at the threshold /
+        unexplained) and the test fails on any unexplained one; the census goes to the report."""
+    from parity_util import report
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    from graphik_amd.utils import dgp
+    d = load_golden(name)
+    robot, graph = make_graph(name)
+    prob = BatchProblem(graph, use_limits=bool(int(d["use_limits"])))
+    assert prob.device_pipeline
+    r = prob.template.prepare_debug(d["T_goal"])
+    lb_d, ub_d = r["lb"].cpu().numpy(), r["ub"].cpu().numpy()
+    assert np.abs(lb_d - d["lb"]).max() < 1e-12 and np.abs(ub_d - d["ub"]).max() < 1e-12
+    Dr = (d["lb"] + 0.9 * (d["ub"] - d["lb"])) ** 2
+    ev_ref = np.linalg.eigvalsh(dgp.gram_from_distance_matrix(Dr))
+    ev_dev = np.sort(r["eig"].cpu().numpy()[:, 0, :], axis=1)
+    assert np.abs(ev_dev - ev_ref).max() <= 1e-10 * np.abs(ev_ref).max()
+    # the reference's own K: LAPACK signs, same numpy/LAPACK build as the capture
+    Y_ref, info_ref = dgp.generate_initialization_batch(d["lb"], d["ub"], graph.dim, d["omega"],
+                                                        canonical=False, return_info=True)
+    assert np.abs(Y_ref @ np.swapaxes(Y_ref, 1, 2) - d["Y_init"] @ np.swapaxes(d["Y_init"], 1, 2)).max() < 1e-8
+    Y_d, K_d = r["Y_init"].cpu().numpy(), r["K"].cpu().numpy()
+    cls = _classify_init(Y_d, K_d, d["Y_init"], info_ref)
+    mask = cls.pop("mask_identical")
+    report(f"device_init_vs_reference/{name}", dict(cls, K_device=K_d.tolist(), K_reference=info_ref["K"].tolist()))
+    assert cls["unexplained"] == 0, cls
+    assert np.all(mask[K_d == info_ref["K"]] | np.any((info_ref["ev_rank"] > 0.25e-8) &
+                                                     (info_ref["ev_rank"] < 4e-8), axis=1)[K_d == info_ref["K"]])
+
+
+@pytest.mark.parametrize("name", SCENARIOS_3D)
+def test_end_to_end_statistics_from_device_init(torch_cuda, name):
+    """The device's initial point differs from the reference's for the goals where MDS's column
+    count depends on LAPACK's eigenvector signs (test above), so end-to-end parity is checked in
+    distribution on 1024 random goals per robot: the whole device pipeline (gik_ik_batch: device
+    init -> solve -> recover) against the oracle started from the REFERENCE-rule initial point
+    (host mirror with LAPACK signs, which reproduces the captured Y_init): convergence rate,
+    outer-iteration quantiles, Hessian products, EE error and success rate (the reference's
+    pos < 0.01 and rot < 0.01)."""
+    from oracle import c_oracle as co
+    from parity_util import report
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    from graphik_amd.utils import dgp
+    robot, graph = make_graph(name)
+    prob = BatchProblem(graph, use_limits=True)
+    B = 1024
+    rng = np.random.RandomState(17)
+    lb_q, ub_q = robot.limits_arrays()
+    Tg = robot.fk_batch(lb_q + (ub_q - lb_q) * rng.rand(B, robot.n))
+    r = prob.template.ik(Tg)
+    its = r["iterations"].cpu().numpy()
+    hv = r["inner_total"].cpu().numpy()
+    stop = r["stop"].cpu().numpy()
+    pos, rot = r["pos_err"].cpu().numpy(), r["rot_err"].cpu().numpy()
+    D, lo, up = prob.assemble(Tg)
+    lbs, ubs = dgp.floyd_warshall_bounds(lo, up)
+    Y_ref = dgp.generate_initialization_batch(lbs, ubs, 3, prob.omega, canonical=False)
+    o = co.rtr_solve_batch(Y_ref, D, prob.omega, prob.psi_L, prob.psi_U, True, fast=True)
+    q_o = prob.joint_variables(o["x"], Tg)
+    pos_o, rot_o = prob.pose_errors(q_o, Tg)
+    its_o, hv_o = o["iterations"], o["inner_total"]
+    conv, conv_o = stop == 0, its_o < 3000
+    succ, succ_o = (pos < 0.01) & (rot < 0.01), (pos_o < 0.01) & (rot_o < 0.01)
+    stats = {
+        "converged": [float(conv.mean()), float(conv_o.mean())],
+        "outer_median": [float(np.median(its)), float(np.median(its_o))],
+        "outer_p90": [float(np.percentile(its, 90)), float(np.percentile(its_o, 90))],
+        "hv_total": [float(hv.sum()), float(hv_o.sum())],
+        "pos_err_median": [float(np.median(pos)), float(np.median(pos_o))],
+        "pos_err_p90": [float(np.percentile(pos, 90)), float(np.percentile(pos_o, 90))],
+        "success": [float(succ.mean()), float(succ_o.mean())],
+        "order": "[device pipeline from device init, oracle from reference-rule init]"}
+    report(f"end_to_end_statistics/{name}", stats)
+    assert abs(conv.mean() - conv_o.mean()) < 0.03
+    assert abs(succ.mean() - succ_o.mean()) < 0.03
+    assert 0.85 < np.median(its) / np.median(its_o) < 1.15
+    assert 0.75 < np.percentile(its, 90) / np.percentile(its_o, 90) < 1.33
+    assert 0.8 < hv.sum() / hv_o.sum() < 1.25
+    assert 0.7 < np.median(pos) / np.median(pos_o) < 1.4
 
 
 @pytest.mark.parametrize("name", ["lwa4d", "planar10_limits_halfpi"])

@@ -399,7 +399,7 @@ def ur10_table():
     robot, graph = load_ur10()
     for idx, obs in enumerate(table_environment()):
         graph.add_spherical_obstacle(f"o{idx}", obs[0], obs[1])
-    run_scenario("ur10_table", robot, graph, seeds=[0], traj_goals=1, loop_goals=0)
+    run_scenario("ur10_table", robot, graph, seeds=list(range(8)), traj_goals=8, loop_goals=0)
 
 
 if __name__ == "__main__":
