@@ -34,6 +34,9 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# HIP maps streams onto 4 hardware queues by default, so of more than 3 side streams some share a
+# queue and serialise; the serving measurement keeps 8 batches in flight (read at HIP start-up)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X vector = matrix fp64 peak (spec; fp32 vector 157.3 / 2)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
@@ -77,7 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=1,
                     help="batches in flight in the TIMED region (default 1: steps back to back, the "
                          "headline configuration)")
-    ap.add_argument("--serving-streams", type=int, default=4,
+    ap.add_argument("--serving-streams", type=int, default=8,
                     help="extra, separately labelled measurement after the timed region: the same "
                          "batches issued round-robin on this many HIP streams (0 = skip)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"])
@@ -301,7 +304,7 @@ def main():
     serving = None
     S = args.serving_streams
     if S > 1 and args.streams == 1 and dt / args.steps < 0.5:   # (skipped for multi-second batches)
-        nb = max(4 * S, 8)
+        nb = 4 * S
         sv_streams = [torch.cuda.Stream(dev) for _ in range(S)]
         for s_ in sv_streams:                        # warm the per-stream allocations
             with torch.cuda.stream(s_):

@@ -28,8 +28,12 @@ class TemplateDesc(C.Structure):
         ("rho_prime", C.c_double), ("rho_regularization", C.c_double),
         ("planar_proj_exact", C.c_int32), ("force_block_path", C.c_int32),
         ("waves_per_cu", C.c_int32), ("slice_outer_its", C.c_int32), ("debug_flags", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("solver", C.c_int32), ("cg_minstepsize", C.c_double), ("cg_orth_value", C.c_double),
+        ("cg_beta_type", C.c_int32), ("reserved1", C.c_int32),
     ]
+
+
+SOLVER_TRUST_REGIONS, SOLVER_CONJUGATE_GRADIENT = 0, 1
 
 
 class Stats(C.Structure):
@@ -77,6 +81,7 @@ SYMBOLS = {
     "gik_abi_version": (C.c_int, []),
     "gik_device_count": (C.c_int, []),
     "gik_default_params": (None, [C.POINTER(TemplateDesc)]),
+    "gik_default_cg_params": (None, [C.POINTER(TemplateDesc)]),
     "gik_template_create": (C.c_int, [C.POINTER(TemplateDesc), C.POINTER(C.c_void_p)]),
     "gik_template_destroy": (None, [C.c_void_p]),
     "gik_cost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

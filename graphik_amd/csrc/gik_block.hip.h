@@ -28,6 +28,7 @@ struct BlockCtx {
   static constexpr int NC = (K == 3) ? 3 : 1;
   static constexpr int RS = 4;  // LDS row stride (doubles): 32-byte rows
   static constexpr bool HAS_CK = (K == 3);   // tCG checkpoint (rtr_solve_one "Retrace"): [4][512] doubles
+  static constexpr bool AGE_PRIORITY = false;  // one workgroup per CU: nothing shares its SIMDs
   double *sh_ck;
   __device__ inline void ck_put(int i, double v) { sh_ck[i * BLOCK_NT + tid] = v; }   // own thread only
   __device__ inline double ck_get(int i) const { return sh_ck[i * BLOCK_NT + tid]; }

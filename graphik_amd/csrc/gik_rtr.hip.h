@@ -117,6 +117,15 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
     if (dbg & 2) bad = true;
 
     while (!bad) {
+      // Wave priority grows with the age of the problem (s_setprio, 0..3).  Two waves share a SIMD's
+      // fp64 pipe; the arbiter issues the ready wave of highest priority, so a long-running problem
+      // -- the batch's critical path -- keeps close to the speed of a lone wave while the younger
+      // co-resident problem fills the issue slots it leaves.  Results do not depend on it.
+      if constexpr (Ctx::AGE_PRIORITY) {
+        if (kiter == 32) __builtin_amdgcn_s_setprio(1);
+        else if (kiter == 128) __builtin_amdgcn_s_setprio(2);
+        else if (kiter == 512) __builtin_amdgcn_s_setprio(3);
+      }
       // -------------- _truncated_conjugate_gradient (trust_region.py:436-599) -------------
       const double Delta2 = Delta * Delta;
       bool reuse = false;
@@ -488,6 +497,7 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         if (slice_its > 0 && ++slice_count >= slice_its) { paused = true; break; }
     }
     if (bad) stop = 2;
+    if constexpr (Ctx::AGE_PRIORITY) __builtin_amdgcn_s_setprio(0);
     if (prof && lead) {
       dbg_buf[0] = (double)prof_tcg;
       dbg_buf[1] = (double)inner_total;

@@ -19,6 +19,7 @@
 
 #include "gik_block.hip.h"
 #include "gik_prep.hip.h"
+#include "gik_rcg.hip.h"
 #include "gik_rtr.hip.h"
 #include "gik_wave.hip.h"
 #include "graphik_amd.h"
@@ -94,6 +95,7 @@ struct SolveArgs {
             // 16 = rerun tCG after every rejected step instead of resuming from the checkpoint
   double *dbg_buf;
   Params p;
+  CgParams cg;   // solver == GIK_SOLVER_CONJUGATE_GRADIENT (rcg_* kernels)
   // Time slicing (slice_its > 0): a problem that has not met a stopping rule after slice_its outer
   // iterations is written back (x in Y_out, SliceState) and re-queued behind everything that is
   // waiting, so that all problems advance at about the same rate and the long ones -- unknown in
@@ -168,6 +170,57 @@ __global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
       s.inner_total = inner_total;
       s.stop = stop;
       s.n_accept = n_accept;
+      s.inner_executed = ro.inner_executed;
+      s.reserved = 0;
+      a.stats[b] = s;
+    }
+  }
+}
+
+// Riemannian conjugate gradients (the reference's alternative solver), same persistent scheme
+template <int K, int MAXDEG>
+__global__ void __launch_bounds__(WAVE, 2) rcg_wave_kernel(SolveArgs a) {
+  using Ctx = WaveCtx<K, MAXDEG>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int NK = a.N * K;
+  double *sh_tiles = smem;
+  double *sh_tgt = smem + K * Ctx::TILE;
+  uint32_t *sh_meta = reinterpret_cast<uint32_t *>(sh_tgt + ((a.T + 1) & ~1));
+  stage_lds<Ctx>(sh_tiles, sh_meta, a.slot_meta, lane, MAXDEG, K);
+  Ctx cx;
+  cx.init(lane, a.N, sh_tiles, sh_tgt, sh_meta);
+  int pass = 0;
+  for (;;) {
+    // Same claim as rtr_wave_kernel, INCLUDING the static block -> problem alternative (dbg & 1).
+    // With only the atomic claim in the loop the compiler treats the loop exit as divergent and
+    // wraps this loop and the solver loop inside it in exec masks, under which the wave-wide
+    // reductions dead-lock (measured: a hang at maxiter = 3; an "+s" asm pin on b does not help).
+    // Checked in the ISA: no s_andn2_b64 exec besides the two strided copy loops.
+    int b = 0;
+    if (a.dbg & 1) {
+      b = (int)blockIdx.x + pass * (int)gridDim.x;
+      ++pass;
+    } else {
+      if (lane == 0) b = (int)atomicAdd(a.work_counter, 1u);
+      b = __builtin_amdgcn_readlane(b, 0);  // lane 0 explicitly, independent of exec
+    }
+    if (UNI(b >= a.B)) break;
+    for (int t = lane; t < a.T; t += WAVE) sh_tgt[t] = a.targets[(size_t)b * a.T + t];
+    __builtin_amdgcn_wave_barrier();
+    cx.load_slot_records();
+    double x = cx.active ? a.Y_init[(size_t)b * NK + lane] : 0.0;
+    RtrOut ro;
+    rcg_solve_one<K>(cx, a.cg, a.trace, a.has_trace, b, x, ro);
+    if (cx.active) a.Y_out[(size_t)b * NK + lane] = x;
+    if (lane == 0) {
+      gik_stats s;
+      s.f = ro.f;
+      s.gradnorm = ro.gradnorm;
+      s.iterations = ro.iterations;
+      s.inner_total = ro.inner_total;
+      s.stop = ro.stop;
+      s.n_accept = ro.n_accept;
       s.inner_executed = ro.inner_executed;
       s.reserved = 0;
       a.stats[b] = s;
@@ -310,6 +363,42 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
       s.reserved = 0;
       a.stats[b] = s;
       if (a.slice_its > 0) __hip_atomic_fetch_add(a.q_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(BLOCK_NT) rcg_block_kernel(SolveArgs a, int SL, int SLE) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int sh_b;
+  const int tid = threadIdx.x;
+  const int NK = a.N * K;
+  BlockCtx<K> cx;
+  block_stage<K>(cx, smem, a.slot_meta, a.N, a.T, SL, SLE);
+  double *sh_tgt = smem + 3 * BLOCK_MAXN * BlockCtx<K>::RS;
+  for (;;) {
+    if (tid == 0) sh_b = (int)atomicAdd(a.work_counter, 1u);
+    __syncthreads();
+    const int b = sh_b;
+    __syncthreads();
+    if (UNI(b >= a.B)) break;
+    for (int t = tid; t < a.T; t += BLOCK_NT) sh_tgt[t] = a.targets[(size_t)b * a.T + t];
+    __syncthreads();
+    double x = cx.active ? a.Y_init[(size_t)b * NK + cx.node * K + cx.part] : 0.0;
+    RtrOut ro;
+    rcg_solve_one<K>(cx, a.cg, a.trace, a.has_trace, b, x, ro);
+    if (cx.active) a.Y_out[(size_t)b * NK + cx.node * K + cx.part] = x;
+    if (tid == 0) {
+      gik_stats s;
+      s.f = ro.f;
+      s.gradnorm = ro.gradnorm;
+      s.iterations = ro.iterations;
+      s.inner_total = ro.inner_total;
+      s.stop = ro.stop;
+      s.n_accept = ro.n_accept;
+      s.inner_executed = ro.inner_executed;
+      s.reserved = 0;
+      a.stats[b] = s;
     }
   }
 }
@@ -559,11 +648,13 @@ struct Variant {
   int K, maxdeg;
   solve_fn solve;        // theta == 1 (reference default)
   solve_fn solve_theta;  // any theta
+  solve_fn solve_cg;     // ConjugateGradient
   kat_fn kat;
   lds_fn lds;
 };
 #define GIK_VARIANT(K, D) \
-  {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, kat_wave_kernel<K, D>, lds_bytes_of<K, D>}
+  {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
+   lds_bytes_of<K, D>}
 static const Variant kVariants[] = {GIK_VARIANT(3, 9),  GIK_VARIANT(3, 10), GIK_VARIANT(3, 20), GIK_VARIANT(2, 6),
                                     GIK_VARIANT(2, 16), GIK_VARIANT(2, 31)};
 
@@ -571,6 +662,8 @@ static const Variant kVariants[] = {GIK_VARIANT(3, 9),  GIK_VARIANT(3, 10), GIK_
 
 struct gik_template {
   int N, K, T, maxdeg;
+  int solver;
+  gik::CgParams cg;
   gik::Params p;
   const gik::Variant *variant;
   uint32_t *d_slot_meta;
@@ -653,7 +746,18 @@ void gik_default_params(gik_template_desc *d) {
   d->waves_per_cu = 0;
   d->slice_outer_its = -1;
   d->debug_flags = 0;
-  d->reserved0 = 0;
+  d->solver = GIK_SOLVER_TRUST_REGIONS;
+  d->cg_minstepsize = 1e-10;    // riemannian_solver.py:56
+  d->cg_orth_value = 10e10;     // :57
+  d->cg_beta_type = 3;          // :58  BetaTypes[3] = HagerZhang
+  d->reserved1 = 0;
+}
+
+void gik_default_cg_params(gik_template_desc *d) {
+  gik_default_params(d);
+  d->solver = GIK_SOLVER_CONJUGATE_GRADIENT;
+  d->mingradnorm = 1e-9;        // riemannian_solver.py:53
+  d->maxiter = 100000;          // :55  (10e4)
 }
 
 int gik_template_create(const gik_template_desc *d, gik_template **out) {
@@ -661,6 +765,9 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   if (!d || !out) return fail("null argument");
   if (d->abi_version != GIK_ABI_VERSION) return fail("ABI version mismatch");
   if (d->k != 2 && d->k != 3) return fail("k must be 2 or 3");
+  if (d->solver != GIK_SOLVER_TRUST_REGIONS && d->solver != GIK_SOLVER_CONJUGATE_GRADIENT)
+    return fail("solver must be GIK_SOLVER_TRUST_REGIONS or GIK_SOLVER_CONJUGATE_GRADIENT");
+  if (d->cg_beta_type < 0 || d->cg_beta_type > 3) return fail("cg_beta_type must be 0..3");
   bool is_block = d->N * d->k > WAVE || d->N > 32 || d->force_block_path != 0;
   if (d->N < 2 || d->N > BLOCK_MAXN) return fail("N must be in [2, 128]");
   if (d->n_terms < 1 || d->n_terms > 65535) return fail("n_terms out of range");
@@ -757,6 +864,13 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   t->p.maxinner = d->maxinner;
   t->p.mininner = d->mininner;
   t->p.planar_proj_exact = d->planar_proj_exact;
+  t->solver = d->solver;
+  t->cg.mingradnorm = d->mingradnorm;
+  t->cg.minstepsize = d->cg_minstepsize;
+  t->cg.orth_value = d->cg_orth_value;
+  t->cg.maxiter = d->maxiter;
+  t->cg.beta_type = d->cg_beta_type;
+  t->cg.planar_proj_exact = d->planar_proj_exact;
   t->dbg = d->debug_flags;
   t->wpc_override = std::max(0, d->waves_per_cu);
   t->slice_its = d->slice_outer_its < 0 ? 256 : d->slice_outer_its;
@@ -774,9 +888,11 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
     delete t;
     return fail("graph too large for the LDS-resident block path");
   }
+  const bool cg = d->solver == GIK_SOLVER_CONJUGATE_GRADIENT;
   const void *solve_kernel =
-      is_block ? (d->k == 3 ? (const void *)rtr_block_kernel<3> : (const void *)rtr_block_kernel<2>)
-               : (const void *)var->solve;
+      is_block ? (cg ? (d->k == 3 ? (const void *)rcg_block_kernel<3> : (const void *)rcg_block_kernel<2>)
+                     : (d->k == 3 ? (const void *)rtr_block_kernel<3> : (const void *)rtr_block_kernel<2>))
+               : (const void *)(cg ? var->solve_cg : var->solve);
   if (is_block && t->smem_bytes > 48 * 1024) {
     // more than the default dynamic-LDS allowance: opt in for exactly what this template needs
     const void *fns[2] = {solve_kernel, d->k == 3 ? (const void *)kat_block_kernel<3>
@@ -1057,6 +1173,7 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   a.T = t->T;
   a.B = B;
   a.p = t->p;
+  a.cg = t->cg;
   a.dbg = t->dbg;
   a.dbg_buf = nullptr;
 #ifdef GIK_DEV
@@ -1071,21 +1188,26 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   gik_template *mt = const_cast<gik_template *>(t);  // the counter ring is the only mutable part
   a.work_counter = t->d_counters + (mt->next_counter.fetch_add(1) % kCounterRing);
   HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned int), (hipStream_t)stream));
-  // Persistent waves per CU.  A wavefront that shares its SIMD runs ~20 % slower, and the batch
-  // time of a few thousand goals is the run time of its slowest problem, so small batches get one
-  // wave per SIMD; with more than ~12 problems per SIMD the throughput of two waves per SIMD wins
-  // (measured on LWA4D, kernel ms at 1 / 2 waves per SIMD: B=4096 120 / 130, B=8192 151 / 173,
-  // B=16384 196 / 172-185).
+  // Persistent waves per CU: as many as fit (two per SIMD at 249 VGPRs).  Two waves share a SIMD's
+  // fp64 pipe and each runs 20-50 % slower than alone, which used to cost small batches -- whose
+  // time is that of their slowest problem -- more than the extra throughput returned; with the age
+  // priority of rtr_solve_one the old problems keep a lone wave's speed next to a young neighbour
+  // (kernel ms at 1 / 2 waves per SIMD without, and 2 per SIMD with priorities -- LWA4D B=4096:
+  // 116.9 / 132.4 / 116.3, B=16384: 190.6 / 196.7 / 187.7; KUKA B=8192: 182.8 / 156.4 / 155.4,
+  // B=65536: 755.7 / 545.5 / 544.2).
+  // Small batches still get one wave per SIMD: their time is the run time of the few problems that
+  // go to maxiter, and two of THOSE on one SIMD (equal priority) slow each other down -- at 4096
+  // LWA4D goals a third of the launches drew such a pair (128 instead of 116 ms).
   int wpc = t->waves_per_cu;
-  // (planar problems are short and uniform: full occupancy is 7 % faster there)
-  if (!t->is_block && t->K == 3 && wpc > 4 && (long long)B <= 12LL * 4 * t->n_cu) wpc = 4;
+  if (!t->is_block && t->K == 3 && wpc > 4 && (long long)B <= 6LL * 4 * t->n_cu) wpc = 4;
   if (t->wpc_override > 0) wpc = t->wpc_override;
   const int grid = std::min(B, t->n_cu * wpc);
   // Time slicing (workgroup-per-problem kernel): only when there are more problems than resident
   // workgroups (otherwise everything starts at once anyway).  Slice length: the handle's
   // slice_outer_its, 0 disables.  Measured on UR10 + table, 4096 goals: 8.9 -> 7.7 s.
   int slice = t->slice_its;
-  if (!t->is_block || B <= grid || (a.dbg & 1) || slice <= 0 || t->p.maxiter <= slice) slice = 0;
+  const bool cg = t->solver == GIK_SOLVER_CONJUGATE_GRADIENT;
+  if (!t->is_block || cg || B <= grid || (a.dbg & 1) || slice <= 0 || t->p.maxiter <= slice) slice = 0;
   a.slice_its = slice;
   a.q_tail = a.q_done = nullptr;
   a.q_ids = nullptr;
@@ -1120,15 +1242,15 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     HIP_OK(hipMemsetAsync(a.q_seq, 0xFF, cap * 4, (hipStream_t)stream));
   }
   if (t->is_block) {
-    if (t->K == 3)
-      hipLaunchKernelGGL(rtr_block_kernel<3>, dim3(grid), dim3(BLOCK_NT), t->smem_bytes,
-                         (hipStream_t)stream, a, t->SL, t->SLE);
-    else
-      hipLaunchKernelGGL(rtr_block_kernel<2>, dim3(grid), dim3(BLOCK_NT), t->smem_bytes,
-                         (hipStream_t)stream, a, t->SL, t->SLE);
+    void (*kern)(SolveArgs, int, int) =
+        cg ? (t->K == 3 ? rcg_block_kernel<3> : rcg_block_kernel<2>)
+           : (t->K == 3 ? rtr_block_kernel<3> : rtr_block_kernel<2>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK_NT), t->smem_bytes, (hipStream_t)stream, a, t->SL,
+                       t->SLE);
   } else {
-    hipLaunchKernelGGL(t->p.theta == 1.0 ? t->variant->solve : t->variant->solve_theta, dim3(grid),
-                       dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(cg ? t->variant->solve_cg
+                          : (t->p.theta == 1.0 ? t->variant->solve : t->variant->solve_theta),
+                       dim3(grid), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
   }
   HIP_OK(hipGetLastError());
   if (sw) {

@@ -324,6 +324,7 @@ struct WaveCtx {
   // LDS carve: K tiles | targets[T] | slot meta (MAXDEG*64 u32) | slot records (MAXDEG*64 x 16 B)
   //            | tCG checkpoint (4 x 64 doubles, k = 3: see "Retrace" in rtr_solve_one)
   static constexpr bool HAS_CK = (K == 3);
+  static constexpr bool AGE_PRIORITY = true;   // waves of different problems share a SIMD (rtr_solve_one)
   __host__ __device__ static constexpr size_t lds_bytes(int T) {
     return sizeof(double) * ((size_t)K * TILE + (size_t)((T + 1) & ~1)) +
            sizeof(uint32_t) * (size_t)MAXDEG * WAVE + sizeof(SlotRec) * (size_t)MAXDEG * WAVE +

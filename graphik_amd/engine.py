@@ -88,20 +88,31 @@ class Template:
         self.targets_static = None if targets_static is None else \
             np.ascontiguousarray(targets_static, dtype=np.float64)
         d = _ffi.TemplateDesc()
-        self.lib.gik_default_params(C.byref(d))
+        params = dict(params or {})
+        self.solver = params.pop("solver", "TrustRegions")
+        if self.solver == "ConjugateGradient":      # riemannian_solver.py:51-59
+            self.lib.gik_default_cg_params(C.byref(d))
+        elif self.solver == "TrustRegions":
+            self.lib.gik_default_params(C.byref(d))
+        else:
+            raise ValueError("params[\"solver\"] must be one of 'ConjugateGradient', 'TrustRegions'")
         d.N, d.k, d.n_terms = self.N, self.k, self.T
         d.term_i = self.term_i.ctypes.data_as(C.POINTER(C.c_int32))
         d.term_j = self.term_j.ctypes.data_as(C.POINTER(C.c_int32))
         d.term_kind = self.term_kind.ctypes.data_as(C.POINTER(C.c_int32))
-        for key, val in (params or {}).items():
+        alias = {"minstepsize": "cg_minstepsize", "orth_value": "cg_orth_value", "beta_type": "cg_beta_type"}
+        for key, val in params.items():
+            key = alias.get(key, key)
             if not hasattr(d, key):
                 raise KeyError(f"unknown solver parameter {key!r}")
-            setattr(d, key, val)
+            setattr(d, key, int(val) if key in ("maxiter", "cg_beta_type") else val)
         self.params = {f: getattr(d, f) for f in ("mingradnorm", "maxiter", "maxinner", "mininner",
                                                    "theta", "kappa", "rho_prime",
                                                    "rho_regularization", "planar_proj_exact",
                                                    "force_block_path", "waves_per_cu",
-                                                   "slice_outer_its", "debug_flags")}
+                                                   "slice_outer_its", "debug_flags", "cg_minstepsize",
+                                                   "cg_orth_value", "cg_beta_type")}
+        self.params["solver"] = self.solver
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _ffi.check(self.lib.gik_template_create(C.byref(d), C.byref(h)))

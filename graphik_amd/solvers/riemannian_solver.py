@@ -22,7 +22,9 @@ from ..utils.constants import POS
 from ..utils.lie import as_matrix
 
 _STOP_REASONS = {0: "Terminated - min grad norm reached", 1: "Terminated - max iterations reached",
-                 2: "Terminated - NaN encountered"}
+                 2: "Terminated - NaN encountered", 3: "Terminated - min stepsize reached"}
+# riemannian_solver.py:24-26 (indexable like pymanopt's make_enum: BetaTypes[3] == "HagerZhang")
+BetaTypes = ["FletcherReeves", "PolakRibiere", "HestenesStiefel", "HagerZhang"]
 
 
 class RiemannianSolver:
@@ -32,15 +34,24 @@ class RiemannianSolver:
         self.dim = graph.dim
         self.N = graph.number_of_nodes()
         solver_type = params.get("solver", "TrustRegions")
-        if solver_type == "ConjugateGradient":
-            raise NotImplementedError("only the TrustRegions solver is implemented on the GPU "
-                                      "(the reference's ConjugateGradient is pymanopt's)")
-        if solver_type != "TrustRegions":
+        if solver_type == "TrustRegions":
+            # riemannian_solver.py:44-50
+            self.tr_params = {"mingradnorm": params.get("mingradnorm", 0.5 * 1e-9),
+                              "maxiter": int(params.get("maxiter", 3000)),
+                              "theta": params.get("theta", 1.0), "kappa": params.get("kappa", 0.1)}
+        elif solver_type == "ConjugateGradient":
+            # riemannian_solver.py:51-59: pymanopt's ConjugateGradient (HagerZhang, adaptive line
+            # search), on the device like the trust-region solver (rcg_* kernels)
+            beta = params.get("beta_type", 3)
+            if isinstance(beta, str):
+                beta = BetaTypes.index(beta)
+            self.tr_params = {"solver": "ConjugateGradient",
+                              "mingradnorm": params.get("mingradnorm", 1e-9),
+                              "maxiter": int(params.get("maxiter", 10e4)),
+                              "minstepsize": params.get("minstepsize", 1e-10),
+                              "orth_value": params.get("orth_value", 10e10), "beta_type": int(beta)}
+        else:
             raise ValueError("params[\"solver\"] must be one of 'ConjugateGradient', 'TrustRegions'")
-        # riemannian_solver.py:44-50
-        self.tr_params = {"mingradnorm": params.get("mingradnorm", 0.5 * 1e-9),
-                          "maxiter": int(params.get("maxiter", 3000)),
-                          "theta": params.get("theta", 1.0), "kappa": params.get("kappa", 0.1)}
         for k in ("maxinner", "mininner", "rho_prime", "rho_regularization", "planar_proj_exact",
                   "force_block_path", "waves_per_cu", "slice_outer_its", "debug_flags"):
             if k in params:
@@ -118,6 +129,8 @@ class RiemannianSolver:
                 "iterations": res["iterations"].cpu().numpy(),
                 "inner_iterations": res["inner_total"].cpu().numpy(),
                 "stop": res["stop"].cpu().numpy()}
+        if T.solver == "ConjugateGradient":      # pymanopt's final_values carry the last step size
+            info["costevals"] = info.pop("inner_iterations")
         if not batched:
             info = {k: (v[0] if k == "x" else v[0].item()) for k, v in info.items()}
             info["stop_reason"] = _STOP_REASONS[int(info["stop"])]

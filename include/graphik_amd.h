@@ -75,8 +75,19 @@ typedef struct {
                                 iterations; -1 = default (256), 0 = no time slicing            */
   int32_t debug_flags;       /* developer flags (gik_solve.hip: SolveArgs::dbg); 16 = rerun tCG
                                 after a rejected step instead of resuming from the checkpoint  */
-  int32_t reserved0;
+  /* which of the reference's two solvers gik_solve_batch runs (riemannian_solver.py:40-65):
+   * GIK_SOLVER_TRUST_REGIONS (default) or GIK_SOLVER_CONJUGATE_GRADIENT = pymanopt 0.2.5
+   * ConjugateGradient + LineSearchAdaptive as configured at :51-59.  The CG defaults of
+   * mingradnorm / maxiter differ (1e-9 / 100000): gik_default_cg_params() sets them.           */
+  int32_t solver;
+  double cg_minstepsize;     /* 1e-10                                                         */
+  double cg_orth_value;      /* 10e10                                                         */
+  int32_t cg_beta_type;      /* 0 FletcherReeves, 1 PolakRibiere, 2 HestenesStiefel, 3 HagerZhang
+                                (the reference passes BetaTypes[3])                           */
+  int32_t reserved1;
 } gik_template_desc;
+
+enum { GIK_SOLVER_TRUST_REGIONS = 0, GIK_SOLVER_CONJUGATE_GRADIENT = 1 };
 
 typedef struct gik_template gik_template; /* opaque handle, immutable after creation */
 
@@ -87,7 +98,8 @@ typedef struct {
   int32_t iterations;  /* outer (trust-region) iterations                                 */
   int32_t inner_total; /* tCG iterations as the reference counts them (sum of numit+1); a
                           "model increased" exit costs one product more than it reports  */
-  int32_t stop;        /* 0: gradnorm < mingradnorm, 1: maxiter, 2: NaN encountered       */
+  int32_t stop;        /* 0: gradnorm < mingradnorm, 1: maxiter, 2: NaN encountered,
+                          3: step size < cg_minstepsize (ConjugateGradient only)           */
   int32_t n_accept;    /* accepted steps                                                  */
   int32_t inner_executed; /* Hessian products actually evaluated: after a rejected step the
                           reference's next tCG solve repeats the previous one up to the smaller
@@ -113,6 +125,14 @@ int gik_device_count(void);
 
 /* Set `desc->` trust-region fields to the reference defaults. */
 void gik_default_params(gik_template_desc *desc);
+/* ... and for params["solver"] = "ConjugateGradient" (riemannian_solver.py:51-59): solver,
+ * mingradnorm 1e-9, maxiter 10e4, cg_minstepsize 1e-10, cg_orth_value 10e10, cg_beta_type 3.
+ * With this solver gik_stats reports: iterations = CG iterations, inner_total = inner_executed =
+ * cost evaluations of the line searches, n_accept = line searches that moved, stop = 0 gradnorm,
+ * 1 maxiter, 2 NaN, 3 step size below cg_minstepsize; gik_trace columns: d_f_before / d_gradnorm_after
+ * = cost / |grad| before step q, d_Delta = step size, d_numit = cost evaluations of the line
+ * search, d_stop = direction reset to -grad, d_accept = the line search moved.               */
+void gik_default_cg_params(gik_template_desc *desc);
 
 int gik_template_create(const gik_template_desc *desc, gik_template **out);
 void gik_template_destroy(gik_template *t);

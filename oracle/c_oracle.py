@@ -34,6 +34,19 @@ class Traj(C.Structure):
                 ("accept", C.POINTER(C.c_int))]
 
 
+class CgParams(C.Structure):
+    _fields_ = [("mingradnorm", C.c_double), ("maxiter", C.c_int), ("minstepsize", C.c_double),
+                ("orth_value", C.c_double), ("beta_type", C.c_int), ("use_limits", C.c_int),
+                ("ls_contraction", C.c_double), ("ls_suff_decr", C.c_double),
+                ("ls_initial_stepsize", C.c_double), ("ls_maxiter", C.c_int)]
+
+
+class CgTraj(C.Structure):
+    _fields_ = [("cap", C.c_int), ("len", C.c_int), ("f", C.POINTER(C.c_double)),
+                ("gradnorm", C.POINTER(C.c_double)), ("stepsize", C.POINTER(C.c_double)),
+                ("costevals", C.POINTER(C.c_int))]
+
+
 def build(force=False):
     """Compile oracle/_build/*.so with gcc (idempotent)."""
     so = os.path.join(_HERE, "_build", "libgik_oracle.so")
@@ -71,6 +84,9 @@ def lib(fast=False):
         L.gik_o_rtr_solve.argtypes = [_dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int64, C.c_int,
                                       C.c_int, C.POINTER(Params), C.POINTER(Result),
                                       C.POINTER(Traj)]
+        L.gik_o_cg_default_params.argtypes = [C.POINTER(CgParams)]
+        L.gik_o_cg_solve.argtypes = [_dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int64, C.c_int, C.c_int,
+                                     C.POINTER(CgParams), C.POINTER(Result), C.POINTER(CgTraj)]
         L.gik_o_rtr_solve_batch.argtypes = [_dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int64, C.c_int,
                                             C.c_int, C.c_int, C.POINTER(Params),
                                             C.POINTER(Result), C.c_int]
@@ -235,6 +251,43 @@ def rtr_solve_batch(Y_init, D_goal, omega, psi_L, psi_U, use_limits=True, nthrea
            "iterations": np.array([r.iterations for r in res]),
            "inner_total": np.array([r.inner_total for r in res])}
     return out
+
+
+def cg_solve(Y_init, D_goal, omega, psi_L=None, psi_U=None, use_limits=True, traj_cap=0, **kw):
+    """RiemannianSolver(graph, {"solver": "ConjugateGradient"}).solve (riemannian_solver.py:51-59):
+    pymanopt 0.2.5 ConjugateGradient (HagerZhang) + LineSearchAdaptive, restated in C."""
+    Y = _c(Y_init).copy()
+    N, k = Y.shape
+    omega = _c(omega)
+    if use_limits:
+        psi_L, psi_U = _c(psi_L), _c(psi_U)
+        inds = limit_inds(omega, psi_L, psi_U)
+    else:
+        psi_L, psi_U = np.zeros_like(omega), np.zeros_like(omega)
+        inds = np.nonzero(np.triu(omega))
+    ii, jj = _inds(inds)
+    p = CgParams()
+    lib().gik_o_cg_default_params(C.byref(p))
+    p.use_limits = int(use_limits)
+    for k_, v in kw.items():
+        setattr(p, k_, v)
+    res = Result()
+    tr, keep = None, {}
+    if traj_cap > 0:
+        tr = CgTraj()
+        tr.cap = traj_cap
+        for name, ct, dt in (("f", C.c_double, np.float64), ("gradnorm", C.c_double, np.float64),
+                             ("stepsize", C.c_double, np.float64), ("costevals", C.c_int, np.int32)):
+            keep[name] = np.zeros(traj_cap, dtype=dt)
+            setattr(tr, name, keep[name].ctypes.data_as(C.POINTER(ct)))
+    rc = lib().gik_o_cg_solve(Y, _c(D_goal), omega, psi_L, psi_U, ii, jj, len(ii), N, k, C.byref(p),
+                              C.byref(res), C.byref(tr) if tr else None)
+    assert rc == 0
+    info = {"x": Y, "f(x)": res.f, "gradnorm": res.gradnorm, "iterations": res.iterations,
+            "costevals": res.inner_total, "stop": res.stop}
+    if tr:
+        info["traj"] = {k_: v[: tr.len] for k_, v in keep.items()}
+    return info
 
 
 def bound_smoothing(lower, upper):

@@ -611,6 +611,145 @@ int gik_o_rtr_solve_batch(double *Y, const double *D_goal, const double *omega,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Riemannian conjugate gradients: the reference's params["solver"] = "ConjugateGradient"
+ * (graphik/solvers/riemannian_solver.py:51-59) is pymanopt 0.2.5's ConjugateGradient
+ * (pymanopt/solvers/conjugate_gradient.py, a port of Manopt's conjugategradient.m) with
+ * LineSearchAdaptive (pymanopt/solvers/linesearch.py) -- a THIRD-PARTY dependency that is not under
+ * /root/reference (setup.py:20 pins pymanopt == 0.2.5).  Restated here from the published
+ * algorithm; manifold methods are the reference's (fixed_rank_psd_sym.py): inner/norm = Frobenius,
+ * retr(Y, U) = Y + U, transp(Y, Z, U) = proj(Z, U), egrad2rgrad = identity, precon = identity.
+ * Pinned by tests/golden/cg.npz (tools/capture_golden_cg.py: the reference's solve() driving the
+ * same restatement in Python, tools/ref_shims/pymanopt/solvers).
+ * ------------------------------------------------------------------------------------------ */
+void gik_o_cg_default_params(gik_o_cg_params *p) {
+  p->mingradnorm = 1e-9;   /* riemannian_solver.py:53 */
+  p->maxiter = 100000;     /* :55  (10e4)             */
+  p->minstepsize = 1e-10;  /* :56                     */
+  p->orth_value = 10e10;   /* :57                     */
+  p->beta_type = 3;        /* :58  BetaTypes[3] = HagerZhang */
+  p->use_limits = 1;
+  /* LineSearchAdaptive defaults */
+  p->ls_contraction = 0.5;
+  p->ls_suff_decr = 0.5;
+  p->ls_maxiter = 10;
+  p->ls_initial_stepsize = 1.0;
+}
+
+int gik_o_cg_solve(double *Y, const double *D_goal, const double *omega, const double *psi_L,
+                   const double *psi_U, const int64_t *ii, const int64_t *jj, int64_t n_inds,
+                   int N, int k, const gik_o_cg_params *p, gik_o_result *res, gik_o_cg_traj *traj) {
+  const int n = N * k;
+  double *buf = (double *)malloc(sizeof(double) * (size_t)n * 9);
+  if (!buf) return -1;
+  double *grad = buf, *desc = buf + n, *newx = buf + 2 * n, *newgrad = buf + 3 * n,
+         *oldgrad = buf + 4 * n, *tdesc = buf + 5 * n, *diff = buf + 6 * n, *tmp = buf + 7 * n,
+         *trial = buf + 8 * n;
+  ctx_t c = {D_goal, omega, psi_L, psi_U, ii, jj, n_inds, N, k, p->use_limits, tmp};
+  double *x = Y;
+  int iter = 0, stop = 1, costevals_total = 0;
+  double stepsize = NAN;
+  double cost = ctx_cost(&c, x);
+  ctx_grad(&c, x, grad);
+  double gradnorm = sqrt(dot(grad, grad, n));      /* man.norm */
+  double gradPgrad = dot(grad, grad, n);            /* precon = identity: Pgrad = grad */
+  for (int t = 0; t < n; ++t) desc[t] = -grad[t];
+  double oldalpha = 0.0;
+  int have_oldalpha = 0;                            /* LineSearchAdaptive._oldalpha = None */
+  if (traj) traj->len = 0;
+  for (;;) {
+    /* _check_stopping_criterion(time0, gradnorm=gradnorm, iter=iter + 1, stepsize=stepsize):
+     * maxtime (not reproduced), iter >= maxiter, gradnorm < mingradnorm, stepsize < minstepsize */
+    if (iter + 1 >= p->maxiter) { stop = 1; break; }
+    if (gradnorm < p->mingradnorm) { stop = 0; break; }
+    if (stepsize < p->minstepsize) { stop = 3; break; }      /* NaN compares false */
+    if (isnan(cost) || isnan(gradnorm)) { stop = 2; break; } /* (pymanopt would spin to maxiter) */
+    double df0 = dot(grad, desc, n);
+    if (df0 >= 0) {                                 /* not a descent direction: restart */
+      for (int t = 0; t < n; ++t) desc[t] = -grad[t];
+      df0 = -gradPgrad;
+    }
+    /* ---- LineSearchAdaptive.search(objective, man, x, d, f0, df0) ---- */
+    const double norm_d = sqrt(dot(desc, desc, n));
+    double alpha = have_oldalpha ? oldalpha : p->ls_initial_stepsize / norm_d;
+    for (int t = 0; t < n; ++t) trial[t] = alpha * desc[t];
+    for (int t = 0; t < n; ++t) newx[t] = x[t] + trial[t];   /* man.retr(x, alpha * d) */
+    double newf = ctx_cost(&c, newx);
+    int cost_evaluations = 1;
+    while (newf > cost + p->ls_suff_decr * alpha * df0 && cost_evaluations <= p->ls_maxiter) {
+      alpha *= p->ls_contraction;
+      for (int t = 0; t < n; ++t) trial[t] = alpha * desc[t];
+      for (int t = 0; t < n; ++t) newx[t] = x[t] + trial[t];
+      newf = ctx_cost(&c, newx);
+      cost_evaluations += 1;
+    }
+    if (newf > cost) {
+      alpha = 0;
+      for (int t = 0; t < n; ++t) newx[t] = x[t];
+    }
+    stepsize = alpha * norm_d;
+    oldalpha = (cost_evaluations == 2) ? alpha : 2 * alpha;
+    have_oldalpha = 1;
+    costevals_total += cost_evaluations;
+    if (traj && traj->len < traj->cap) {
+      int q = traj->len++;
+      if (traj->f) traj->f[q] = cost;
+      if (traj->gradnorm) traj->gradnorm[q] = gradnorm;
+      if (traj->stepsize) traj->stepsize[q] = stepsize;
+      if (traj->costevals) traj->costevals[q] = cost_evaluations;
+    }
+    /* ---- new point ---- */
+    const double newcost = ctx_cost(&c, newx);
+    ctx_grad(&c, newx, newgrad);
+    const double newgradnorm = sqrt(dot(newgrad, newgrad, n));
+    const double newgradPnewgrad = dot(newgrad, newgrad, n);
+    gik_o_proj(newx, grad, N, k, oldgrad);           /* oldgrad = man.transp(x, newx, grad) */
+    const double orth_grads = dot(oldgrad, newgrad, n) / newgradPnewgrad;
+    if (fabs(orth_grads) >= p->orth_value) {         /* Powell restart */
+      for (int t = 0; t < n; ++t) desc[t] = -newgrad[t];
+    } else {
+      gik_o_proj(newx, desc, N, k, tdesc);           /* desc_dir = man.transp(x, newx, desc_dir) */
+      double beta;
+      if (p->beta_type == 0) {                       /* FletcherReeves */
+        beta = newgradPnewgrad / gradPgrad;
+      } else if (p->beta_type == 1) {                /* PolakRibiere */
+        for (int t = 0; t < n; ++t) diff[t] = newgrad[t] - oldgrad[t];
+        beta = fmax(0.0, dot(newgrad, diff, n) / gradPgrad);
+      } else if (p->beta_type == 2) {                /* HestenesStiefel */
+        for (int t = 0; t < n; ++t) diff[t] = newgrad[t] - oldgrad[t];
+        const double den = dot(diff, tdesc, n);
+        beta = (den == 0.0) ? 1.0 : fmax(0.0, dot(newgrad, diff, n) / den);
+      } else {                                       /* HagerZhang */
+        for (int t = 0; t < n; ++t) diff[t] = newgrad[t] - oldgrad[t];
+        /* Poldgrad = man.transp(x, newx, Pgrad) = oldgrad; Pdiff = Pnewgrad - Poldgrad = diff */
+        const double deno = dot(diff, tdesc, n);
+        double numo = dot(diff, newgrad, n);
+        numo -= 2 * dot(diff, diff, n) * dot(tdesc, newgrad, n) / deno;
+        beta = numo / deno;
+        const double desc_dir_norm = sqrt(dot(tdesc, tdesc, n));
+        const double eta_HZ = -1 / (desc_dir_norm * fmin(0.01, gradnorm));
+        beta = fmax(beta, eta_HZ);
+      }
+      for (int t = 0; t < n; ++t) desc[t] = -newgrad[t] + beta * tdesc[t];
+    }
+    for (int t = 0; t < n; ++t) x[t] = newx[t];
+    cost = newcost;
+    for (int t = 0; t < n; ++t) grad[t] = newgrad[t];
+    gradnorm = newgradnorm;
+    gradPgrad = newgradPnewgrad;
+    iter += 1;
+  }
+  if (res) {
+    res->f = cost;
+    res->gradnorm = gradnorm;
+    res->iterations = iter;
+    res->inner_total = costevals_total;
+    res->stop = stop;
+  }
+  free(buf);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * graphik/utils/dgp.py:192-231   bound_smoothing
  * The reference runs networkx all-pairs Bellman-Ford on the doubled graph H (u, u' = "us"):
  *   u->u' 0 ; u->v', v->u' -LOWER ; u<->v UPPER ; u'<->v' UPPER            (:203-211)

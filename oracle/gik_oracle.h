@@ -95,6 +95,32 @@ int gik_o_rtr_solve_batch(double *Y, const double *D_goal, const double *omega,
                           const int64_t *jj, int64_t n_inds, int N, int k, int B,
                           const gik_o_params *p, gik_o_result *res, int nthreads);
 
+/* ---- Riemannian conjugate gradients: pymanopt 0.2.5 ConjugateGradient + LineSearchAdaptive as
+ * configured by graphik/solvers/riemannian_solver.py:51-59 (third-party, restated; see the .c) ---- */
+typedef struct {
+  double mingradnorm;   /* 1e-9   */
+  int maxiter;          /* 100000 */
+  double minstepsize;   /* 1e-10  */
+  double orth_value;    /* 10e10  */
+  int beta_type;        /* 0 FletcherReeves, 1 PolakRibiere, 2 HestenesStiefel, 3 HagerZhang */
+  int use_limits;
+  double ls_contraction, ls_suff_decr, ls_initial_stepsize;   /* 0.5, 0.5, 1 */
+  int ls_maxiter;                                             /* 10 */
+} gik_o_cg_params;
+void gik_o_cg_default_params(gik_o_cg_params *p);
+typedef struct {
+  int cap, len;
+  double *f;          /* cost before step q                         */
+  double *gradnorm;   /* ||grad|| before step q                     */
+  double *stepsize;   /* alpha * ||d|| the line search returned     */
+  int *costevals;     /* cost evaluations of that line search       */
+} gik_o_cg_traj;
+/* res->inner_total = cost evaluations of all line searches; res->stop: 0 gradnorm, 1 maxiter,
+ * 2 NaN, 3 minstepsize */
+int gik_o_cg_solve(double *Y, const double *D_goal, const double *omega, const double *psi_L,
+                   const double *psi_U, const int64_t *ii, const int64_t *jj, int64_t n_inds,
+                   int N, int k, const gik_o_cg_params *p, gik_o_result *res, gik_o_cg_traj *traj);
+
 /* ---- pre-processing: graphik/utils/dgp.py ------------------------------------------------- */
 /* bound_smoothing (dgp.py:192-231): all-pairs shortest paths on the doubled graph.  lower /
  * upper are N x N with NaN where the goal graph has no edge.  lb, ub: N x N out.         */

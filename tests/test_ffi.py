@@ -32,6 +32,23 @@ def test_struct_layouts_match_header():
     assert [n for _, n in fields] == [n for n, _ in _ffi.Stats._fields_]
     assert sum(8 if t == "double" else 4 for t, _ in fields) == 40 == C.sizeof(_ffi.Stats)
     assert _ffi.STATS_I32["inner_executed"] == 8 and _ffi.STATS_F64["gradnorm"] == 1
+    # descriptor structs: same fields in the same order with the same scalar types as the header
+    ctype_of = {"double": C.c_double, "int32_t": C.c_int32}
+    for cname, mirror in (("gik_template_desc", _ffi.TemplateDesc), ("gik_pipeline_desc", _ffi.PipelineDesc),
+                          ("gik_prepare_diag", _ffi.PrepareDiag)):
+        nocomment = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        body = re.search(r"typedef struct \{([^}]*)\} %s;" % cname, nocomment).group(1)
+        decl = []
+        for typ, names in re.findall(r"\b(?:const\s+)?(double|int32_t)\s+([^;]+);", body):
+            for nm in names.split(","):
+                nm = nm.strip()
+                decl.append((nm.lstrip("*"), "ptr" if nm.startswith("*") else typ))
+        assert [n for n, _ in decl] == [n for n, _ in mirror._fields_], (cname, decl)
+        for (n, typ), (_, ct) in zip(decl, mirror._fields_):
+            if typ == "ptr":
+                assert C.sizeof(ct) == C.sizeof(C.c_void_p), (cname, n)
+            else:
+                assert ct is ctype_of[typ], (cname, n)
     assert C.sizeof(_ffi.Trace) == 8 + 6 * 8
     assert _ffi.TemplateDesc.N.offset == 4 and _ffi.TemplateDesc.term_i.offset == 16
 

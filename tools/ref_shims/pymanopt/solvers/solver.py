@@ -49,6 +49,17 @@ class Solver(object):
             }
         if self._logverbosity >= 2:
             self._optlog["iterations"] = {"iteration": [], "time": [], "x": [], "f(x)": []}
+            for field in (extraiterfields or []):
+                self._optlog["iterations"][field] = []
+
+    def _append_optlog(self, iteration, x, fx, **kwargs):
+        it = self._optlog["iterations"]
+        it["iteration"].append(iteration)
+        it["time"].append(time.time())
+        it["x"].append(x)
+        it["f(x)"].append(fx)
+        for key in kwargs:
+            it[key].append(kwargs[key])
 
     def _stop_optlog(self, x, objective, stop_reason, time0, stepsize=float("inf"),
                      gradnorm=float("inf"), iter=-1, costevals=-1):

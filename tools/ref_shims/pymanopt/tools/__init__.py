@@ -1,9 +1,6 @@
-def make_enum(name, fields):
-    class _Enum(list):
-        pass
+import collections
 
-    e = _Enum(fields)
-    for i, f in enumerate(fields):
-        setattr(e, f, i)
-    e.__name__ = name
-    return e
+
+def make_enum(name, fields):
+    """pymanopt 0.2.5: a namedtuple instance whose fields hold 0..len-1 (indexable, attributes)."""
+    return collections.namedtuple(name, fields)(*range(len(fields)))
