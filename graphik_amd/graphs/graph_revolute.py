@@ -1,5 +1,5 @@
-"""Distance-geometric problem graph of a 3-D revolute chain
-(graphik/graphs/graph_revolute.py).  Node order p0, x, y, q0, p1, q1, ..., pn, qn."""
+"""Distance-geometric problem graph of a 3-D revolute chain or tree
+(graphik/graphs/graph_revolute.py).  Node order of a chain: p0, x, y, q0, p1, q1, ..., pn, qn."""
 import numpy as np
 
 from .graph_base import ProblemGraph, B_ABOVE, B_BELOW, B_EMPTY, B_FALSE, B_NONE
@@ -32,8 +32,15 @@ def _classify(d, d_max, d_min):
 
 class ProblemGraphRevolute(ProblemGraph):
     def __init__(self, robot, params={}):
-        n = robot.n
-        ids = ["p0", "x", "y", "q0"] + [f"{c}{i}" for i in range(1, n + 1) for c in "pq"]
+        # node order of nx.compose(base, structure) (graph_revolute.py:21-27): the base nodes, then
+        # (p, q) of every joint in the order the end effectors' paths visit them -- for a chain
+        # p0, x, y, q0, p1, q1, ..., pn, qn
+        ids = ["p0", "x", "y", "q0"]
+        for ee in robot.end_effectors:
+            for node in robot.kinematic_map[ROOT][ee]:
+                for name in (node, AUX_PREFIX + node[1:]):
+                    if name not in ids:
+                        ids.append(name)
         super().__init__(robot, params, ids)
         self._base_subgraph()
         self._structure_graph()
@@ -56,20 +63,22 @@ class ProblemGraphRevolute(ProblemGraph):
         tz = trans_axis(self.axis_length, "z")
         robot = self.robot
         pos = {}
-        for i in range(robot.n + 1):
-            cur, aux = f"p{i}", f"q{i}"
-            T0 = robot.nodes[cur]["T0"]
-            pos[cur], pos[aux] = T0.trans, T0.dot(tz).trans
-            d = np.linalg.norm(pos[cur] - pos[aux])
-            self.set_edge(cur, aux, dist=d, lower=d, upper=d, bounded=B_EMPTY)
-            if i:
-                for u in (f"p{i - 1}", f"q{i - 1}"):
-                    for v in (cur, aux):
-                        d = np.linalg.norm(pos[u] - pos[v])
-                        self.set_edge(u, v, dist=d, lower=d, upper=d, bounded=B_EMPTY)
-            if i:
-                self.nodes[cur][TYPE] = [ROBOT]
-                self.nodes[aux][TYPE] = [ROBOT]
+        for ee in robot.end_effectors:
+            k_map = robot.kinematic_map[ROOT][ee]
+            for idx, cur in enumerate(k_map):
+                aux = AUX_PREFIX + cur[1:]
+                T0 = robot.nodes[cur]["T0"]
+                pos[cur], pos[aux] = T0.trans, T0.dot(tz).trans
+                d = np.linalg.norm(pos[cur] - pos[aux])
+                self.set_edge(cur, aux, dist=d, lower=d, upper=d, bounded=B_EMPTY)
+                if idx:
+                    pred = k_map[idx - 1]
+                    for u in (pred, AUX_PREFIX + pred[1:]):
+                        for v in (cur, aux):
+                            d = np.linalg.norm(pos[u] - pos[v])
+                            self.set_edge(u, v, dist=d, lower=d, upper=d, bounded=B_EMPTY)
+                    self.nodes[cur][TYPE] = [ROBOT]
+                    self.nodes[aux][TYPE] = [ROBOT]
 
     def _limit_edge(self, u, v, T0, T1, T2, T_rel, ub):
         """Shared body of set_limits / root_angle_limits (graph_revolute.py:120-165, 196-239)."""
@@ -93,19 +102,22 @@ class ProblemGraphRevolute(ProblemGraph):
     def set_limits(self):
         robot, tz = self.robot, trans_axis(self.axis_length, "z")
         limited = []
-        for idx in range(2, robot.n + 1):
-            cur, mid, prev = f"p{idx}", f"p{idx - 1}", f"p{idx - 2}"
-            for a0 in "pq":
-                for a1 in "pq":
-                    T0, T1, T2 = (robot.nodes[k]["T0"] for k in (prev, mid, cur))
-                    if a0 == AUX_PREFIX:
-                        T0 = T0.dot(tz)
-                    if a1 == AUX_PREFIX:
-                        T2 = T2.dot(tz)
-                    code = self._limit_edge(f"{a0}{idx - 2}", f"{a1}{idx}", T0, T1, T2,
-                                            T1.inv().dot(T2), robot.ub[cur])
-                    if code in (B_BELOW, B_ABOVE):
-                        limited.append(cur)
+        for ee in robot.end_effectors:                     # graph_revolute.py:180-241
+            k_map = robot.kinematic_map[ROOT][ee]
+            for idx in range(2, len(k_map)):
+                cur, prev = k_map[idx], k_map[idx - 2]
+                mid = robot.kinematic_map[prev][cur][1]
+                for a0 in "pq":
+                    for a1 in "pq":
+                        T0, T1, T2 = (robot.nodes[k]["T0"] for k in (prev, mid, cur))
+                        if a0 == AUX_PREFIX:
+                            T0 = T0.dot(tz)
+                        if a1 == AUX_PREFIX:
+                            T2 = T2.dot(tz)
+                        code = self._limit_edge(f"{a0}{prev[1:]}", f"{a1}{cur[1:]}", T0, T1, T2,
+                                                T1.inv().dot(T2), robot.ub[cur])
+                        if code in (B_BELOW, B_ABOVE):
+                            limited.append(cur)
         self.limited_joints = limited
 
     def root_angle_limits(self):
@@ -132,13 +144,15 @@ class ProblemGraphRevolute(ProblemGraph):
 
     def joint_variables(self, G, T_final=None):
         """Joint angles of a realisation (graph_revolute.py:251-318).  G: graph with POS on every
-        node, or an N x 3 array in node order."""
+        node, or an N x 3 array in node order.  T_final: pose of the end effector, or a dict
+        {end effector: pose} (robots with several end effectors)."""
         P = G if isinstance(G, np.ndarray) else G.positions()
         T_fin = None
         if T_final is not None:
-            T_fin = as_matrix(T_final[self.robot.end_effectors[0]] if isinstance(T_final, dict)
-                              else T_final)
-        q = joint_variables_revolute_batch(self, P[None], None if T_fin is None else T_fin[None])[0]
+            if not isinstance(T_final, dict):
+                T_final = {self.robot.end_effectors[0]: T_final}
+            T_fin = {ee: as_matrix(T)[None] for ee, T in T_final.items()}
+        q = joint_variables_revolute_batch(self, P[None], T_fin)[0]
         return self.robot.array_to_q(q)
 
     def get_pose(self, joint_angles, query_node):
@@ -148,11 +162,14 @@ class ProblemGraphRevolute(ProblemGraph):
 
 def joint_variables_revolute_batch(graph, P, T_final=None, tol=1e-10):
     """Vectorised restatement of ProblemGraphRevolute.joint_variables over B realisations.
-    P [B,N,3] (node order of `graph`), T_final [B,4,4] or None  ->  q [B,n]."""
+    P [B,N,3] (node order of `graph`); T_final: [B,4,4] poses of the (first) end effector, a dict
+    {end effector: [B,4,4]}, or None  ->  q [B,n] (columns p1..pn)."""
     robot = graph.robot
     n, a = robot.n, graph.axis_length
     ix = graph.index
     B = P.shape[0]
+    if T_final is not None and not isinstance(T_final, dict):
+        T_final = {robot.end_effectors[0]: T_final}
     unit = lambda v: v / np.where(np.linalg.norm(v, axis=-1, keepdims=True) == 0, 1.0,
                                   np.linalg.norm(v, axis=-1, keepdims=True))
     p0 = P[:, ix("p0")]
@@ -160,27 +177,34 @@ def joint_variables_revolute_batch(graph, P, T_final=None, tol=1e-10):
     R = np.stack((x, -y, z), axis=-1)                      # columns x, -y, z  (:270-279)
     Rt = np.swapaxes(R, 1, 2)
     to_base = lambda v: np.einsum("bij,bj->bi", Rt, v - p0)  # B.inv().dot(v)
-    T0 = robot.T0_array()
     Tz = np.identity(4)
     Tz[2, 3] = a
-    T_prev = np.broadcast_to(as_matrix(robot.T_base), (B, 4, 4)).copy()
+    T = {ROOT: np.broadcast_to(as_matrix(robot.T_base), (B, 4, 4)).copy()}
     theta = np.zeros((B, n))
-    T_rel = None
-    for idx in range(1, n + 1):
-        inv_prev0 = np.linalg.inv(T0[idx - 1])
-        T_rel = inv_prev0 @ T0[idx]
-        qs_0 = (inv_prev0 @ T0[idx] @ Tz)[:3, 3]
-        pc, qc = P[:, ix(f"p{idx}")], P[:, ix(f"q{idx}")]
-        qn = to_base(pc + unit(qc - pc))
-        qs = np.einsum("bji,bj->bi", T_prev[:, :3, :3], qn - T_prev[:, :3, 3])
-        theta[:, idx - 1] = np.arctan2(qs_0[0] * qs[:, 1] - qs_0[1] * qs[:, 0],
+    for ee in robot.end_effectors:                         # :285-316, one path per end effector
+        k_map = robot.kinematic_map[ROOT][ee]
+        T_rel = None
+        for idx in range(1, len(k_map)):
+            cur, pred = k_map[idx], k_map[idx - 1]
+            T0_prev, T0_cur = robot.nodes[pred]["T0"].as_matrix(), robot.nodes[cur]["T0"].as_matrix()
+            inv_prev0 = np.linalg.inv(T0_prev)
+            T_rel = inv_prev0 @ T0_cur
+            qs_0 = (inv_prev0 @ T0_cur @ Tz)[:3, 3]
+            pc, qc = P[:, ix(cur)], P[:, ix(AUX_PREFIX + cur[1:])]
+            qn = to_base(pc + unit(qc - pc))
+            T_prev = T[pred]
+            qs = np.einsum("bji,bj->bi", T_prev[:, :3, :3], qn - T_prev[:, :3, 3])
+            col = int(cur[1:]) - 1
+            theta[:, col] = np.arctan2(qs_0[0] * qs[:, 1] - qs_0[1] * qs[:, 0],
                                        qs_0[0] * qs[:, 0] + qs_0[1] * qs[:, 1])   # :308
-        c, s = np.cos(theta[:, idx - 1]), np.sin(theta[:, idx - 1])
-        Rz = np.zeros((B, 4, 4))
-        Rz[:, 0, 0], Rz[:, 0, 1], Rz[:, 1, 0], Rz[:, 1, 1] = c, -s, s, c
-        Rz[:, 2, 2] = Rz[:, 3, 3] = 1.0
-        T_prev = T_prev @ Rz @ T_rel                                                   # :310
-    if T_final is not None and np.linalg.norm(np.cross(T_rel[:3, 3], [0, 0, 1])) < tol:  # :314
-        T_th = np.linalg.inv(T_prev) @ T_final
-        theta[:, n - 1] = wraptopi(theta[:, n - 1] + np.arctan2(T_th[:, 1, 0], T_th[:, 0, 0]))
+            c, s = np.cos(theta[:, col]), np.sin(theta[:, col])
+            Rz = np.zeros((B, 4, 4))
+            Rz[:, 0, 0], Rz[:, 0, 1], Rz[:, 1, 0], Rz[:, 1, 1] = c, -s, s, c
+            Rz[:, 2, 2] = Rz[:, 3, 3] = 1.0
+            T[cur] = T_prev @ Rz @ T_rel                                               # :310
+        if T_final is not None and ee in T_final and \
+                np.linalg.norm(np.cross(T_rel[:3, 3], [0, 0, 1])) < tol:               # :314
+            T_th = np.linalg.inv(T[ee]) @ T_final[ee]
+            col = int(ee[1:]) - 1
+            theta[:, col] = wraptopi(theta[:, col] + np.arctan2(T_th[:, 1, 0], T_th[:, 0, 0]))
     return theta

@@ -38,12 +38,14 @@ class RobotRevolute(Robot):
         as_dict = lambda v: v if isinstance(v, dict) else list_to_variable_dict(flatten([list(v)]))
         a, d, al, th = (as_dict(params[k]) for k in ("a", "d", "alpha", "theta"))
         T = {ROOT: SE3.identity()}
-        for i in range(1, self.n + 1):
+        for node in self.joint_ids:            # robot_revolute.py:66-83: links along the path root -> node
+            if node == ROOT:
+                continue
             acc = None
-            for node in self.joint_ids[1:i + 1][::-1]:  # right-to-left product of the links
-                link = _dh(a[node], al[node], d[node], th[node], params["modified_dh"])
+            for link_node in self.kinematic_map[ROOT][node][1:][::-1]:   # right-to-left product
+                link = _dh(a[link_node], al[link_node], d[link_node], th[link_node], params["modified_dh"])
                 acc = link if acc is None else link.dot(acc)
-            T[f"p{i}"] = acc
+            T[node] = acc
         return T
 
     def pose(self, joint_angles, query_node):
@@ -59,16 +61,18 @@ class RobotRevolute(Robot):
         return np.stack([self.nodes[f"p{i}"]["T0"].as_matrix() for i in range(self.n + 1)])
 
     def fk_batch(self, Q, node_index=None):
-        """Q [B,n] -> T [B,4,4] of frame `node_index` (default: end effector)."""
+        """Q [B,n] (columns p1..pn) -> T [B,4,4] of frame `node_index` (default: the first end
+        effector), along its path from the root."""
         Q = np.atleast_2d(np.asarray(Q, dtype=float))
-        m = self.n if node_index is None else int(node_index)
+        node = self.end_effectors[0] if node_index is None else f"p{int(node_index)}"
+        path = self.kinematic_map[ROOT][node]
         B = Q.shape[0]
         T = np.broadcast_to(self.nodes[ROOT]["T0"].as_matrix(), (B, 4, 4)).copy()
-        for i in range(m):
-            S = self.nodes[f"p{i}"]["S"]
+        for pred, cur in zip(path[:-1], path[1:]):
+            S = self.nodes[pred]["S"]
             v, w = S[:3], S[3:]
             W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=float)
-            th = Q[:, i][:, None, None]
+            th = Q[:, int(cur[1:]) - 1][:, None, None]
             s, c = np.sin(th), np.cos(th)
             I = np.identity(3)
             R = I + s * W + (1 - c) * (W @ W)                       # unit axis
@@ -78,4 +82,4 @@ class RobotRevolute(Robot):
             E[:, :3, 3] = (J @ v)
             E[:, 3, 3] = 1.0
             T = T @ E
-        return T @ self.nodes[f"p{m}"]["T0"].as_matrix()
+        return T @ self.nodes[node]["T0"].as_matrix()

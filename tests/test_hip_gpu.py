@@ -952,3 +952,35 @@ def test_conjugate_gradient_drop_in(torch_cuda):
     assert np.linalg.norm(probot.pose(qs, "p10").trans - Tg.trans) < 1e-4
     with pytest.raises(ValueError):
         RiemannianSolver(pgraph, {"solver": "SteepestDescent"})
+
+
+def test_tree_robot_solve(torch_cuda):
+    """A robot with two end effectors (the tree of the reference's test_joint_variables.py:192-226)
+    through RiemannianSolver.solve on the device -- the reference has no solve_with_riemannian for
+    trees either -- from the captured initial points: cost at the round-off floor like the
+    reference's, and joint_variables() of the solution puts BOTH end effectors on their goals and
+    reproduces the captured angles."""
+    from test_host_layer import tree_robot
+    from graphik_amd.solvers.riemannian_solver import RiemannianSolver
+    from graphik_amd.utils import dgp
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree5.npz"))
+    robot, graph = tree_robot()
+    solver = RiemannianSolver(graph)
+    G = len(d["sol_f"])
+    info = solver.solve(d["sol_D_goal"], d["omega"], use_limits=True, Y_init=d["sol_Y_init"])
+    assert np.all(info["f(x)"] < 1e-18) and np.all(d["sol_f"] < 1e-18) and np.all(info["stop"] == 0)
+    assert np.all(np.abs(info["iterations"] - d["sol_iterations"]) <= 3)
+    for g in range(G):
+        q = {j: d["q_goal"][g][i] for i, j in enumerate(robot.joint_ids[1:])}
+        T_goal = {ee: robot.pose(q, ee) for ee in robot.end_effectors}
+        q_sol = graph.joint_variables(info["x"][g], T_goal)
+        for ee in robot.end_effectors:
+            assert np.linalg.norm(robot.pose(q_sol, ee).trans - T_goal[ee].trans) < 1e-8
+        qa = np.array([q_sol[j] for j in robot.joint_ids[1:]])
+        assert np.abs(np.mod(qa - d["sol_q_sol"][g] + np.pi, 2 * np.pi) - np.pi).max() < 1e-6
+    # same through bounds (device-independent host initialisation) and the no-limits cost
+    Gd = graph.from_pose({ee: robot.pose({j: d["q_goal"][0][i] for i, j in enumerate(robot.joint_ids[1:])}, ee)
+                          for ee in robot.end_effectors})
+    r2 = solver.solve(dgp.distance_matrix_from_graph(Gd), dgp.adjacency_matrix_from_graph(Gd),
+                      bounds=dgp.bound_smoothing(Gd))
+    assert r2["f(x)"] < 1e-18

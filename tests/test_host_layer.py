@@ -211,3 +211,70 @@ def test_problem_cache_key_follows_graph_content():
     assert graph_fingerprint(g) not in (one, moved)
     _, g_lim = load_ur10(limits=(-np.pi / 2 * np.ones(6), np.pi / 2 * np.ones(6)))
     assert graph_fingerprint(g_lim) != base
+
+
+# ---- tree-structured robots (several end effectors) ---------------------------------------------
+def tree_robot():
+    """The robot of the reference's tests/test_joint_variables.py:192-226."""
+    from graphik_amd.robots import RobotRevolute
+    from graphik_amd.graphs import ProblemGraphRevolute
+    pi = np.pi
+    params = {"a": {"p1": 0, "p2": -0.612, "p3": -0.612, "p4": -0.5732, "p5": -0.5732},
+              "alpha": {"p1": pi / 2, "p2": 0, "p3": 0, "p4": 0, "p5": 0},
+              "d": {"p1": 0.1237, "p2": 0, "p3": 0, "p4": 0, "p5": 0},
+              "theta": {"p1": 0, "p2": 0, "p3": 0, "p4": 0, "p5": 0}, "modified_dh": False,
+              "parents": {"p0": ["p1"], "p1": ["p2", "p3"], "p2": ["p4"], "p3": ["p5"]}, "num_joints": 5}
+    robot = RobotRevolute(params)
+    return robot, ProblemGraphRevolute(robot)
+
+
+def test_tree_robot_graph_matches_reference():
+    """Topology, node order, zero-configuration frames and every edge attribute of the problem
+    graph of a two-end-effector tree against tests/golden/tree5.npz (tools/capture_golden_tree.py:
+    the reference's RobotRevolute / ProblemGraphRevolute on the same parameters)."""
+    from graphik_amd.graphs.graph_base import B_ABSENT, B_EMPTY, B_NOEDGE
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree5.npz"))
+    robot, graph = tree_robot()
+    assert robot.joint_ids == list(d["joint_ids"]) and robot.end_effectors == list(d["end_effectors"])
+    assert graph.node_ids == list(d["node_ids"]) and not robot.is_chain
+    T0 = np.stack([robot.nodes[j]["T0"].as_matrix() for j in robot.joint_ids])
+    assert np.abs(T0 - d["T0"]).max() < 1e-14
+    for key, M in (("G_dist", graph.dist), ("G_lower", graph.lower), ("G_upper", graph.upper)):
+        assert np.array_equal(np.isnan(M), np.isnan(d[key])), key
+        assert np.nanmax(np.abs(M - d[key])) < 1e-14, key
+    code = np.where((graph.bounded == B_ABSENT) | (graph.bounded == B_EMPTY), 0, graph.bounded)
+    assert np.array_equal(np.where(graph.bounded == B_NOEDGE, -1, code), d["G_bounded"])
+    pL, pU = graph.distance_bound_matrices()
+    assert np.abs(pL - d["psi_L"]).max() < 1e-14 and np.abs(pU - d["psi_U"]).max() < 1e-14
+
+
+def test_tree_robot_realization_and_joint_variables():
+    """realization(q) and joint_variables(realization(q), T_goal) against the captured reference
+    output, and the reference's own round-trip test (test_joint_variables.py:216-225: 100 random
+    configurations, rtol 1e-5) on this implementation."""
+    from graphik_amd.utils import dgp
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree5.npz"))
+    robot, graph = tree_robot()
+    for s in range(len(d["q_goal"])):
+        np.random.seed(s)
+        q = robot.random_configuration()
+        assert np.allclose([q[j] for j in robot.joint_ids[1:]], d["q_goal"][s], rtol=0, atol=0)
+        T_goal = {ee: robot.pose(q, ee) for ee in robot.end_effectors}
+        for i, ee in enumerate(robot.end_effectors):
+            assert np.abs(T_goal[ee].as_matrix() - d["T_goal"][s][i]).max() < 1e-13
+        G = graph.realization(q)
+        assert np.abs(G.positions() - d["X"][s]).max() < 1e-13
+        q_rec = graph.joint_variables(G, T_goal)
+        assert np.abs(np.array([q_rec[j] for j in robot.joint_ids[1:]]) - d["q_rec"][s]).max() < 1e-10
+        Gd = graph.from_pose(T_goal)
+        if s < len(d["sol_D_goal"]):
+            assert np.abs(dgp.distance_matrix_from_graph(Gd) - d["sol_D_goal"][s]).max() < 1e-13
+            assert np.array_equal(dgp.adjacency_matrix_from_graph(Gd), d["omega"])
+            lb, ub = dgp.bound_smoothing(Gd)
+            assert np.abs(lb - d["sol_lb"][s]).max() < 1e-12 and np.abs(ub - d["sol_ub"][s]).max() < 1e-12
+    np.random.seed(100)
+    for _ in range(100):
+        q_goal = robot.random_configuration()
+        T_goal = {ee: robot.pose(q_goal, ee) for ee in robot.end_effectors}
+        q_rec = graph.joint_variables(graph.realization(q_goal), T_goal)
+        np.testing.assert_allclose([q_goal[k] for k in sorted(q_goal)], [q_rec[k] for k in sorted(q_rec)], rtol=1e-5)
