@@ -71,6 +71,19 @@ class PipelineDesc(C.Structure):
     ]
 
 
+class AnchoredDesc(C.Structure):
+    _fields_ = [
+        ("n_anchor", C.c_int32), ("n_goal_anchor", C.c_int32), ("anchor_pos", C.POINTER(C.c_double)),
+        ("term_target", C.POINTER(C.c_double)), ("n_pin", C.c_int32),
+        ("pin_node", C.POINTER(C.c_int32)), ("pin_anchor", C.POINTER(C.c_int32)),
+        ("pin_kind", C.POINTER(C.c_int32)), ("pin_target", C.POINTER(C.c_double)),
+        ("n_obs", C.c_int32), ("reserved0", C.c_int32), ("obs", C.POINTER(C.c_double)),
+        ("obs_node_mask", C.POINTER(C.c_int32)), ("full_N", C.c_int32), ("reserved1", C.c_int32),
+        ("free_full_index", C.POINTER(C.c_int32)), ("anchor_full_index", C.POINTER(C.c_int32)),
+        ("axis_length", C.c_double),
+    ]
+
+
 class PrepareDiag(C.Structure):
     _fields_ = [("d_lb", C.c_void_p), ("d_ub", C.c_void_p), ("d_eig", C.c_void_p)]
 
@@ -83,6 +96,12 @@ SYMBOLS = {
     "gik_default_params": (None, [C.POINTER(TemplateDesc)]),
     "gik_default_cg_params": (None, [C.POINTER(TemplateDesc)]),
     "gik_template_create": (C.c_int, [C.POINTER(TemplateDesc), C.POINTER(C.c_void_p)]),
+    "gik_template_create_anchored": (C.c_int, [C.POINTER(TemplateDesc), C.POINTER(AnchoredDesc),
+                                               C.POINTER(C.c_void_p)]),
+    "gik_anchored_ws_doubles": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_int]),
+    "gik_anchored_ik_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gik_anchored_last_solve_ms": (C.c_double, [C.c_void_p]),
     "gik_template_destroy": (None, [C.c_void_p]),
     "gik_cost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gik_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -846,4 +846,115 @@ __global__ void recover_kernel(RecoverArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fixed-anchor formulation: glue between the robot-graph pipeline and the anchored
+// solve.  One thread per goal, a few hundred flops each.
+//   anch_init_kernel   : the initial point of the robot graph (prep_wave_kernel, any rigid frame,
+//                        possibly mirrored) is mapped onto the world frame by the orthogonal
+//                        Procrustes fit of its anchor rows to the anchors' world positions; the
+//                        free rows become the anchored start point, the goal anchors are written out.
+//   anch_gather_kernel : free rows + anchors -> full robot-graph point matrix (for recover_kernel).
+struct AnchGlueArgs {
+  const double *T_goal;        // [B][16]
+  const double *Y_full_in;     // [B][full_N*3]   (init: prepare output)
+  double *Y_free;              // [B][Nf*3]       (init: out, gather: in)
+  double *anchor_goal;         // [B][n_goal*3]   (init: out, gather: in)
+  double *Y_full_out;          // [B][full_N*3]   (gather: out)
+  const double *anch_const;    // [ANCH_MAXA][4]
+  const int *free_full;        // [Nf]
+  const int *anchor_full;      // [n_anchor]
+  int B, Nf, full_N, n_anchor, n_goal, goal_row0;
+  double axis_length;
+};
+
+__device__ inline void anchor_world(const AnchGlueArgs &a, const double *Tg, int r, double (&w)[3]) {
+  if (r < a.goal_row0) {
+    for (int c = 0; c < 3; ++c) w[c] = a.anch_const[r * 4 + c];
+  } else {   // goal anchors: p_n = t, q_n = t + axis_length * z  (graph_revolute.py:243-249)
+    const double s = (r - a.goal_row0) ? a.axis_length : 0.0;
+    for (int c = 0; c < 3; ++c) w[c] = Tg[c * 4 + 3] + s * Tg[c * 4 + 2];
+  }
+}
+
+__global__ void anch_init_kernel(AnchGlueArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const double *Tg = a.T_goal + (size_t)b * 16;
+  const double *Y = a.Y_full_in + (size_t)b * a.full_N * 3;
+  // centroids and cross-covariance M = sum_i (w_i - cw)(p_i - cp)^T over the anchors
+  double cp[3] = {0, 0, 0}, cw[3] = {0, 0, 0};
+  for (int r = 0; r < a.n_anchor; ++r) {
+    double w[3];
+    anchor_world(a, Tg, r, w);
+    for (int c = 0; c < 3; ++c) {
+      cp[c] += Y[a.anchor_full[r] * 3 + c];
+      cw[c] += w[c];
+    }
+  }
+  for (int c = 0; c < 3; ++c) {
+    cp[c] /= a.n_anchor;
+    cw[c] /= a.n_anchor;
+  }
+  double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = 0; r < a.n_anchor; ++r) {
+    double w[3];
+    anchor_world(a, Tg, r, w);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) M[i * 3 + j] += (w[i] - cw[i]) * (Y[a.anchor_full[r] * 3 + j] - cp[j]);
+  }
+  // orthogonal polar factor of M (nearest orthogonal matrix, reflections allowed: an MDS embedding
+  // is defined up to a mirror image) by the scaled Newton iteration X <- (g X + X^-T / g) / 2
+  double X[9];
+  for (int t = 0; t < 9; ++t) X[t] = M[t];
+  for (int it = 0; it < 30; ++it) {
+    const double c00 = X[4] * X[8] - X[5] * X[7], c01 = X[5] * X[6] - X[3] * X[8], c02 = X[3] * X[7] - X[4] * X[6];
+    const double c10 = X[2] * X[7] - X[1] * X[8], c11 = X[0] * X[8] - X[2] * X[6], c12 = X[1] * X[6] - X[0] * X[7];
+    const double c20 = X[1] * X[5] - X[2] * X[4], c21 = X[2] * X[3] - X[0] * X[5], c22 = X[0] * X[4] - X[1] * X[3];
+    const double det = X[0] * c00 + X[1] * c01 + X[2] * c02;
+    if (!(fabs(det) > 1e-300)) break;   // degenerate anchors: keep what we have
+    const double id = 1.0 / det;
+    const double IT[9] = {c00 * id, c01 * id, c02 * id, c10 * id, c11 * id, c12 * id, c20 * id, c21 * id, c22 * id};  // X^-T
+    double nx = 0.0, ni = 0.0;
+    for (int t = 0; t < 9; ++t) {
+      nx += X[t] * X[t];
+      ni += IT[t] * IT[t];
+    }
+    const double g = sqrt(sqrt(ni / nx));
+    double diff = 0.0;
+    for (int t = 0; t < 9; ++t) {
+      const double v = 0.5 * (g * X[t] + IT[t] / g);
+      diff += (v - X[t]) * (v - X[t]);
+      X[t] = v;
+    }
+    if (diff < 1e-30) break;
+  }
+  double *Yf = a.Y_free + (size_t)b * a.Nf * 3;
+  for (int f = 0; f < a.Nf; ++f) {
+    const double *p = Y + a.free_full[f] * 3;
+    for (int i = 0; i < 3; ++i)
+      Yf[f * 3 + i] = cw[i] + X[i * 3 + 0] * (p[0] - cp[0]) + X[i * 3 + 1] * (p[1] - cp[1]) + X[i * 3 + 2] * (p[2] - cp[2]);
+  }
+  for (int r = a.goal_row0; r < a.goal_row0 + a.n_goal; ++r) {
+    double w[3];
+    anchor_world(a, Tg, r, w);
+    for (int c = 0; c < 3; ++c) a.anchor_goal[((size_t)b * a.n_goal + (r - a.goal_row0)) * 3 + c] = w[c];
+  }
+}
+
+__global__ void anch_gather_kernel(AnchGlueArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const double *Tg = a.T_goal + (size_t)b * 16;
+  double *Y = a.Y_full_out + (size_t)b * a.full_N * 3;
+  const double *Yf = a.Y_free + (size_t)b * a.Nf * 3;
+  for (int f = 0; f < a.Nf; ++f)
+    for (int c = 0; c < 3; ++c) Y[a.free_full[f] * 3 + c] = Yf[f * 3 + c];
+  for (int r = 0; r < a.n_anchor; ++r) {
+    double w[3];
+    anchor_world(a, Tg, r, w);
+    for (int c = 0; c < 3; ++c) Y[a.anchor_full[r] * 3 + c] = w[c];
+  }
+}
+
 }  // namespace gik

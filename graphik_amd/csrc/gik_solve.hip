@@ -79,6 +79,16 @@ __device__ inline void requeue_work(unsigned int *q_tail, int *q_ids, unsigned i
   __hip_atomic_store(&q_seq[t], (unsigned)B + t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+struct AnchArgs {
+  const double *anch_const;     // [ANCH_MAXA][4] pinned anchor table (goal rows are overwritten per problem)
+  const double *anchor_goal;    // [B][n_goal * 3] per-problem anchor positions
+  const uint32_t *pin_meta;     // [ANCH_PMAX][64] anchor row | kind << 8
+  const double *pin_tgt;        // [ANCH_PMAX][64]
+  const double *obs;            // [n_obs][4] x, y, z, r^2
+  unsigned long long obs_mask;  // bit i: free node i carries the obstacle hinges
+  int n_obs, n_goal, goal_row0; // goal anchors occupy rows goal_row0 .. goal_row0 + n_goal - 1
+};
+
 struct SolveArgs {
   const uint32_t *slot_meta;  // [MAXDEG][64]
   const double *targets;      // [B][T]
@@ -96,6 +106,8 @@ struct SolveArgs {
   double *dbg_buf;
   Params p;
   CgParams cg;   // solver == GIK_SOLVER_CONJUGATE_GRADIENT (rcg_* kernels)
+  // fixed-anchor formulation (anchored templates; see WaveCtx<.., ANCH>)
+  AnchArgs an;
   // Time slicing (slice_its > 0): a problem that has not met a stopping rule after slice_its outer
   // iterations is written back (x in Y_out, SliceState) and re-queued behind everything that is
   // waiting, so that all problems advance at about the same rate and the long ones -- unknown in
@@ -123,9 +135,10 @@ __device__ inline void stage_lds(double *tiles, uint32_t *meta, const uint32_t *
 // counter until the batch is exhausted.  Iteration counts differ by >50x between goals and the
 // hardware hands workgroups to XCDs round-robin, so a static block->problem map leaves whole
 // XCDs idle behind a few stragglers; the queue keeps every SIMD busy until the end.
-template <int K, int MAXDEG, bool THETA_ONE>
+template <int K, int MAXDEG, bool THETA_ONE, bool ANCH = false>
 __global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
-  using Ctx = WaveCtx<K, MAXDEG>;
+  static_assert(!ANCH || K == 3, "the fixed-anchor formulation is 3-D");
+  using Ctx = WaveCtx<K, MAXDEG, ANCH>;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int NK = a.N * K;
@@ -136,6 +149,16 @@ __global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
 
   Ctx cx;
   cx.init(lane, a.N, sh_tiles, sh_tgt, sh_meta);
+  if constexpr (ANCH) {
+    // every target is a template constant here: records, pinned records and the constant rows of
+    // the anchor table are staged once per wave; only the goal anchors change per problem
+    cx.init_anchored(a.an.pin_meta, a.an.obs_mask, a.an.obs, a.an.n_obs);
+    for (int t = lane; t < a.T; t += WAVE) sh_tgt[t] = a.targets[t];
+    for (int t = lane; t < 4 * ANCH_MAXA; t += WAVE) cx.sh_anch[t] = a.an.anch_const[t];
+    __builtin_amdgcn_wave_barrier();
+    cx.load_slot_records();
+    cx.load_pinned_records(a.an.pin_meta, a.an.pin_tgt);
+  }
   const Params &p = a.p;
   int pass = 0;
   for (;;) {
@@ -149,9 +172,16 @@ __global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
     }
     if (UNI(b >= a.B)) break;
 
-    for (int t = lane; t < a.T; t += WAVE) sh_tgt[t] = a.targets[(size_t)b * a.T + t];
-    __builtin_amdgcn_wave_barrier();
-    cx.load_slot_records();
+    if constexpr (ANCH) {
+      if (lane < 3 * a.an.n_goal)
+        cx.sh_anch[(a.an.goal_row0 + lane / 3) * 4 + lane % 3] =
+            a.an.anchor_goal[(size_t)b * 3 * a.an.n_goal + lane];
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      for (int t = lane; t < a.T; t += WAVE) sh_tgt[t] = a.targets[(size_t)b * a.T + t];
+      __builtin_amdgcn_wave_barrier();
+      cx.load_slot_records();
+    }
     double x = cx.active ? a.Y_init[(size_t)b * NK + lane] : 0.0;
 
     RtrOut ro;
@@ -238,11 +268,12 @@ struct KatArgs {
   double *out_f;          // mode 4: cost [B] next to the gradient in `out`
   int N, T, B, mode;      // 0 cost, 1 grad, 2 hess, 3 proj, 4 cost and grad (one pass)
   int planar_proj_exact;
+  AnchArgs an;
 };
 
-template <int K, int MAXDEG>
+template <int K, int MAXDEG, bool ANCH = false>
 __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
-  using Ctx = WaveCtx<K, MAXDEG>;
+  using Ctx = WaveCtx<K, MAXDEG, ANCH>;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
@@ -252,10 +283,20 @@ __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
   uint32_t *sh_meta = reinterpret_cast<uint32_t *>(sh_tgt + ((a.T + 1) & ~1));
   stage_lds<Ctx>(sh_tiles, sh_meta, a.slot_meta, lane, MAXDEG, K);
   for (int t = lane; t < a.T; t += WAVE)
-    sh_tgt[t] = a.targets ? a.targets[(size_t)b * a.T + t] : 0.0;
+    sh_tgt[t] = a.targets ? a.targets[ANCH ? (size_t)t : (size_t)b * a.T + t] : 0.0;
   __builtin_amdgcn_wave_barrier();
   Ctx cx;
   cx.init(lane, a.N, sh_tiles, sh_tgt, sh_meta);
+  if constexpr (ANCH) {
+    cx.init_anchored(a.an.pin_meta, a.an.obs_mask, a.an.obs, a.an.n_obs);
+    for (int t = lane; t < 4 * ANCH_MAXA; t += WAVE) cx.sh_anch[t] = a.an.anch_const[t];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 3 * a.an.n_goal)
+      cx.sh_anch[(a.an.goal_row0 + lane / 3) * 4 + lane % 3] =
+          a.an.anchor_goal[(size_t)b * 3 * a.an.n_goal + lane];
+    __builtin_amdgcn_wave_barrier();
+    cx.load_pinned_records(a.an.pin_meta, a.an.pin_tgt);
+  }
   cx.load_slot_records();
   const double y = cx.active ? a.Y[(size_t)b * NK + lane] : 0.0;
   const double w = (a.W && cx.active) ? a.W[(size_t)b * NK + lane] : 0.0;
@@ -644,6 +685,10 @@ static size_t lds_bytes_of(int T) {
   return WaveCtx<K, D>::lds_bytes(T);
 }
 
+template <int K, int D>
+static size_t lds_bytes_anch(int T) {
+  return WaveCtx<K, D, true>::lds_bytes(T);
+}
 struct Variant {
   int K, maxdeg;
   solve_fn solve;        // theta == 1 (reference default)
@@ -651,17 +696,31 @@ struct Variant {
   solve_fn solve_cg;     // ConjugateGradient
   kat_fn kat;
   lds_fn lds;
+  solve_fn solve_anch;   // fixed-anchor formulation (k = 3, theta == 1), or null
+  kat_fn kat_anch;
+  lds_fn lds_anch;
 };
 #define GIK_VARIANT(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
-   lds_bytes_of<K, D>}
-static const Variant kVariants[] = {GIK_VARIANT(3, 9),  GIK_VARIANT(3, 10), GIK_VARIANT(3, 20), GIK_VARIANT(2, 6),
+   lds_bytes_of<K, D>, nullptr, nullptr, nullptr}
+#define GIK_VARIANT_A(K, D) \
+  {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
+   lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>}
+static const Variant kVariants[] = {GIK_VARIANT_A(3, 9), GIK_VARIANT(3, 10), GIK_VARIANT_A(3, 20), GIK_VARIANT(2, 6),
                                     GIK_VARIANT(2, 16), GIK_VARIANT(2, 31)};
 
 }  // namespace gik
 
 struct gik_template {
   int N, K, T, maxdeg;
+  // fixed-anchor formulation (gik_template_create_anchored)
+  bool anchored = false;
+  hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;   // around the solve kernel of the last gik_anchored_ik_batch
+  gik::AnchArgs an;                 // device pointers + counts (anchor_goal filled per call)
+  double *d_targets_const = nullptr;   // [T] template-constant targets of the free-free terms
+  int full_N = 0, n_anchor = 0;
+  int *d_free_full = nullptr, *d_anchor_full = nullptr;   // node index in the full robot graph
+  double axis_length = 1.0;
   int solver;
   gik::CgParams cg;
   gik::Params p;
@@ -760,9 +819,29 @@ void gik_default_cg_params(gik_template_desc *d) {
   d->maxiter = 100000;          // :55  (10e4)
 }
 
+static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, gik_template **out);
+
 int gik_template_create(const gik_template_desc *d, gik_template **out) {
+  return create_impl(d, nullptr, out);
+}
+
+int gik_template_create_anchored(const gik_template_desc *d, const gik_anchored_desc *ad, gik_template **out) {
+  if (!ad) return gik::fail("null argument");
+  return create_impl(d, ad, out);
+}
+
+static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, gik_template **out) {
   using namespace gik;
   if (!d || !out) return fail("null argument");
+  if (ad) {
+    if (d->k != 3 || d->solver != GIK_SOLVER_TRUST_REGIONS || d->theta != 1.0 || d->force_block_path)
+      return fail("anchored templates: k = 3, TrustRegions, theta = 1, wavefront path");
+    if (ad->n_anchor < 1 || ad->n_anchor > ANCH_MAXA || ad->n_goal_anchor < 0 || ad->n_goal_anchor > ad->n_anchor)
+      return fail("anchored templates: 1 <= n_anchor <= 16, goal anchors are the last rows");
+    if (ad->n_obs < 0 || ad->n_pin < 0 || d->N > 63 || !ad->term_target || !ad->free_full_index ||
+        !ad->anchor_full_index || !ad->anchor_pos)
+      return fail("anchored templates: bad descriptor");
+  }
   if (d->abi_version != GIK_ABI_VERSION) return fail("ABI version mismatch");
   if (d->k != 2 && d->k != 3) return fail("k must be 2 or 3");
   if (d->solver != GIK_SOLVER_TRUST_REGIONS && d->solver != GIK_SOLVER_CONJUGATE_GRADIENT)
@@ -796,9 +875,11 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   std::vector<uint32_t> meta;
   if (!is_block) {   // smallest compiled slot count that holds the busiest node
     for (const Variant &v : kVariants)
-      if (v.K == d->k && v.maxdeg >= maxdeg && (!var || v.maxdeg < var->maxdeg)) var = &v;
+      if (v.K == d->k && v.maxdeg >= maxdeg && (!var || v.maxdeg < var->maxdeg) && (!ad || v.solve_anch))
+        var = &v;
     if (!var) is_block = true;   // a node busier than any wave variant: workgroup-per-problem path
   }
+  if (is_block && ad) return fail("anchored templates need N * k <= 64 free unknowns and at most 20 terms per node");
   if (is_block) {
     // four threads per node, a contiguous quarter of the node's terms each; within a thread the
     // equality terms come first (slots [0, SLE): no kind decoding in the kernels) and the hinge
@@ -883,7 +964,7 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   t->next_counter = 0;
   t->has_pipe = false;
   t->smem_bytes = is_block ? (d->k == 3 ? BlockCtx<3>::lds_bytes(T, SL) : BlockCtx<2>::lds_bytes(T, SL))
-                           : var->lds(T);
+                           : (ad ? var->lds_anch(T) : var->lds(T));
   if (is_block && t->smem_bytes > 160 * 1024) {
     delete t;
     return fail("graph too large for the LDS-resident block path");
@@ -892,7 +973,7 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   const void *solve_kernel =
       is_block ? (cg ? (d->k == 3 ? (const void *)rcg_block_kernel<3> : (const void *)rcg_block_kernel<2>)
                      : (d->k == 3 ? (const void *)rtr_block_kernel<3> : (const void *)rtr_block_kernel<2>))
-               : (const void *)(cg ? var->solve_cg : var->solve);
+               : (const void *)(ad ? var->solve_anch : (cg ? var->solve_cg : var->solve));
   if (is_block && t->smem_bytes > 48 * 1024) {
     // more than the default dynamic-LDS allowance: opt in for exactly what this template needs
     const void *fns[2] = {solve_kernel, d->k == 3 ? (const void *)kat_block_kernel<3>
@@ -925,6 +1006,54 @@ int gik_template_create(const gik_template_desc *d, gik_template **out) {
   }
   t->n_cu = prop.multiProcessorCount;
   t->waves_per_cu = std::max(1, std::min(occ, 32));
+  if (ad) {
+    // ---- fixed-anchor data ----
+    bool ok = true;
+    std::vector<double> tab(4 * ANCH_MAXA, 0.0);
+    for (int r = 0; r < ad->n_anchor; ++r)
+      for (int c = 0; c < 3; ++c) tab[r * 4 + c] = ad->anchor_pos[r * 3 + c];
+    std::vector<uint32_t> pm((size_t)ANCH_PMAX * WAVE, 0u);
+    std::vector<double> pt((size_t)ANCH_PMAX * WAVE, 0.0);
+    std::vector<int> cnt(N, 0);
+    for (int q = 0; q < ad->n_pin; ++q) {
+      const int i = ad->pin_node[q], r = ad->pin_anchor[q], kind = ad->pin_kind[q];
+      if (i < 0 || i >= N || r < 0 || r >= ad->n_anchor || kind < GIK_TERM_EQ || kind > GIK_TERM_UPPER || cnt[i] >= ANCH_PMAX) {
+        ok = false;
+        break;
+      }
+      for (int c = 0; c < 3; ++c) {      // every lane of the node walks all of the node's pinned terms
+        pm[(size_t)cnt[i] * WAVE + i * 3 + c] = (uint32_t)r | ((uint32_t)kind << 8);
+        pt[(size_t)cnt[i] * WAVE + i * 3 + c] = ad->pin_target[q];
+      }
+      ++cnt[i];
+    }
+    unsigned long long mask = 0;
+    for (int i = 0; i < N && ad->obs_node_mask; ++i)
+      if (ad->obs_node_mask[i]) mask |= 1ull << i;
+    AnchArgs an;
+    an.anch_const = ok ? upload(t, tab.data(), tab.size(), ok) : nullptr;
+    an.pin_meta = upload(t, pm.data(), pm.size(), ok);
+    an.pin_tgt = upload(t, pt.data(), pt.size(), ok);
+    an.obs = ad->n_obs ? upload(t, ad->obs, (size_t)ad->n_obs * 4, ok) : nullptr;
+    an.anchor_goal = nullptr;
+    an.obs_mask = mask;
+    an.n_obs = ad->n_obs;
+    an.n_goal = ad->n_goal_anchor;
+    an.goal_row0 = ad->n_anchor - ad->n_goal_anchor;
+    t->an = an;
+    t->d_targets_const = const_cast<double *>(upload(t, ad->term_target, (size_t)T, ok));
+    t->d_free_full = const_cast<int *>(upload(t, ad->free_full_index, (size_t)N, ok));
+    t->d_anchor_full = const_cast<int *>(upload(t, ad->anchor_full_index, (size_t)ad->n_anchor, ok));
+    t->full_N = ad->full_N;
+    t->n_anchor = ad->n_anchor;
+    t->axis_length = ad->axis_length;
+    t->anchored = true;
+    if (!ok) {
+      gik_template_destroy(t);
+      return fail("anchored templates: bad pinned term (node / anchor / kind out of range, or more than 8 per node) "
+                  "or device upload failed");
+    }
+  }
   if (t->dbg & 32)
       fprintf(stderr, "gik_template_create: N=%d k=%d T=%d %s maxdeg=%d lds=%zu B occupancy=%d per CU, %d CUs\n",
               t->N, t->K, t->T, is_block ? "block" : "wave", is_block ? 0 : t->variant->maxdeg,
@@ -938,6 +1067,8 @@ void gik_template_destroy(gik_template *t) {
   if (t->d_slot_meta) (void)hipFree(t->d_slot_meta);
   if (t->d_counters) (void)hipFree(t->d_counters);
   for (void *p : t->pipe_allocs) (void)hipFree(p);
+  if (t->ev_solve0) (void)hipEventDestroy(t->ev_solve0);
+  if (t->ev_solve1) (void)hipEventDestroy(t->ev_solve1);
   if (t->prep_done) (void)hipEventDestroy(t->prep_done);
   for (auto &w : t->slice_ws) {
     if (w.base) (void)hipFree(w.base);
@@ -1091,6 +1222,69 @@ int gik_ik_batch(const gik_template *t, const double *d_T_goal, int B, double *d
   return gik_recover_batch(t, d_Y, d_T_goal, B, d_q, d_pos_err, d_rot_err, stream);
 }
 
+size_t gik_anchored_ws_doubles(const gik_template *anch, const gik_template *base, int B) {
+  if (!anch || !base || !anch->anchored || B < 0) return 0;
+  return (size_t)B * ((size_t)base->T + (size_t)base->N * 3 + (size_t)anch->N * 3 + (size_t)anch->an.n_goal * 3);
+}
+
+int gik_anchored_ik_batch(const gik_template *anch, const gik_template *base, const double *d_T_goal, int B,
+                          double *d_ws, double *d_Y_full, gik_stats *d_stats, double *d_q,
+                          double *d_pos_err, double *d_rot_err, void *stream) {
+  using namespace gik;
+  if (!anch || !base || !anch->anchored || B < 0) return fail("bad argument");
+  if (!base->has_pipe || base->K != 3 || base->N != anch->full_N)
+    return fail("the base template must be the robot graph (full_N nodes) with its pipeline attached");
+  if (B == 0) return 0;
+  if (!d_T_goal || !d_ws || !d_Y_full || !d_stats || !d_q || !d_pos_err || !d_rot_err) return fail("null buffer");
+  double *tg_base = d_ws;
+  double *Y_full0 = tg_base + (size_t)B * base->T;
+  double *Y_free = Y_full0 + (size_t)B * base->N * 3;
+  double *goal = Y_free + (size_t)B * anch->N * 3;
+  // initial point of the robot graph (bound smoothing + MDS, obstacles play no part in it) ...
+  int rc = gik_prepare_batch(base, d_T_goal, B, tg_base, Y_full0, nullptr, stream);
+  if (rc) return rc;
+  AnchGlueArgs g;
+  g.T_goal = d_T_goal;
+  g.Y_full_in = Y_full0;
+  g.Y_free = Y_free;
+  g.anchor_goal = goal;
+  g.Y_full_out = d_Y_full;
+  g.anch_const = anch->an.anch_const;
+  g.free_full = anch->d_free_full;
+  g.anchor_full = anch->d_anchor_full;
+  g.B = B;
+  g.Nf = anch->N;
+  g.full_N = anch->full_N;
+  g.n_anchor = anch->n_anchor;
+  g.n_goal = anch->an.n_goal;
+  g.goal_row0 = anch->an.goal_row0;
+  g.axis_length = anch->axis_length;
+  // ... mapped onto the world frame by its anchors; free rows = anchored start point
+  hipLaunchKernelGGL(anch_init_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, g);
+  HIP_OK(hipGetLastError());
+  gik_template *ma = const_cast<gik_template *>(anch);   // (timing events: diagnostics only)
+  if (!ma->ev_solve0) {
+    (void)hipEventCreate(&ma->ev_solve0);
+    (void)hipEventCreate(&ma->ev_solve1);
+  }
+  (void)hipEventRecord(ma->ev_solve0, (hipStream_t)stream);
+  rc = gik_solve_batch(anch, Y_free, goal, B, Y_free, d_stats, nullptr, stream);
+  if (rc) return rc;
+  (void)hipEventRecord(ma->ev_solve1, (hipStream_t)stream);
+  hipLaunchKernelGGL(anch_gather_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, g);
+  HIP_OK(hipGetLastError());
+  return gik_recover_batch(base, d_Y_full, d_T_goal, B, d_q, d_pos_err, d_rot_err, stream);
+}
+
+double gik_anchored_last_solve_ms(const gik_template *anch) {
+  if (!anch || !anch->ev_solve0) return -1.0;
+  float ms = -1.0f;
+  if (hipEventSynchronize(anch->ev_solve1) != hipSuccess ||
+      hipEventElapsedTime(&ms, anch->ev_solve0, anch->ev_solve1) != hipSuccess)
+    return -1.0;
+  return (double)ms;
+}
+
 static int launch_kat(const gik_template *t, int mode, const double *d_Y, const double *d_W,
                       const double *d_targets, int B, double *d_out, void *stream,
                       double *d_out_f = nullptr) {
@@ -1110,6 +1304,19 @@ static int launch_kat(const gik_template *t, int mode, const double *d_Y, const 
   a.B = B;
   a.mode = mode;
   a.planar_proj_exact = t->p.planar_proj_exact;
+  if (t->anchored && mode == 3) {          // the anchors fix the gauge: proj is the identity
+    HIP_OK(hipMemcpyAsync(d_out, d_W, sizeof(double) * (size_t)B * t->N * t->K, hipMemcpyDeviceToDevice,
+                          (hipStream_t)stream));
+    return 0;
+  }
+  if (t->anchored) {
+    a.an = t->an;
+    a.an.anchor_goal = d_targets;          // (anchored templates: the per-problem input is the goal anchors)
+    a.targets = t->d_targets_const;
+    hipLaunchKernelGGL(t->variant->kat_anch, dim3(B), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
   if (t->is_block) {
     if (t->K == 3)
       hipLaunchKernelGGL(kat_block_kernel<3>, dim3(B), dim3(BLOCK_NT), t->smem_bytes,
@@ -1174,6 +1381,11 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   a.B = B;
   a.p = t->p;
   a.cg = t->cg;
+  if (t->anchored) {
+    a.an = t->an;
+    a.an.anchor_goal = d_targets;          // anchored templates: per-problem goal anchors [B][n_goal*3]
+    a.targets = t->d_targets_const;
+  }
   a.dbg = t->dbg;
   a.dbg_buf = nullptr;
 #ifdef GIK_DEV
@@ -1248,8 +1460,9 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK_NT), t->smem_bytes, (hipStream_t)stream, a, t->SL,
                        t->SLE);
   } else {
-    hipLaunchKernelGGL(cg ? t->variant->solve_cg
-                          : (t->p.theta == 1.0 ? t->variant->solve : t->variant->solve_theta),
+    hipLaunchKernelGGL(t->anchored ? t->variant->solve_anch
+                       : cg        ? t->variant->solve_cg
+                                   : (t->p.theta == 1.0 ? t->variant->solve : t->variant->solve_theta),
                        dim3(grid), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
   }
   HIP_OK(hipGetLastError());

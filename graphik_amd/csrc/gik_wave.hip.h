@@ -308,7 +308,20 @@ struct Row {
 };
 
 // ---- per-wave problem context -------------------------------------------------------------
-template <int K, int MAXDEG>
+// ANCH: fixed-anchor formulation (opt-in): nodes with a known position (base frame,
+// goal nodes, obstacles) are constants instead of rows of Y, and every free node may carry
+//   * up to ANCH_PMAX "pinned" point-to-anchor terms (equality / hinge terms to base and goal
+//     anchors, own target each; anchor positions in a small LDS table), and
+//   * lower hinges against ALL n_obs spherical obstacles (graph_base.py:205-211 as intended:
+//     |p_i - o_k| >= r_k), walked by every lane at once so that the obstacle data is wave-uniform
+//     (scalar loads from global memory, no LDS).
+// An anchor does not move, so these terms touch cost(), commit() and the diagonal blocks `bsum` of
+// the Hessian only -- the Hessian-vector product costs what it costs without obstacles.  Anchors
+// fix the gauge: the search space is Euclidean (no horizontal projection, Q = 0).
+constexpr int ANCH_PMAX = 8;
+constexpr int ANCH_MAXA = 16;   // rows of the pinned-anchor table
+
+template <int K, int MAXDEG, bool ANCH = false>
 struct WaveCtx {
   static constexpr int RS = (K == 3) ? 6 : 2;  // LDS row stride in doubles (48 B / 16 B)
   static constexpr int NC = (K == 3) ? 3 : 1;  // independent entries of the skew matrix
@@ -328,7 +341,43 @@ struct WaveCtx {
   __host__ __device__ static constexpr size_t lds_bytes(int T) {
     return sizeof(double) * ((size_t)K * TILE + (size_t)((T + 1) & ~1)) +
            sizeof(uint32_t) * (size_t)MAXDEG * WAVE + sizeof(SlotRec) * (size_t)MAXDEG * WAVE +
-           (HAS_CK ? sizeof(double) * 4 * WAVE : 0);
+           (HAS_CK ? sizeof(double) * 4 * WAVE : 0) +
+           (ANCH ? sizeof(double) * 4 * ANCH_MAXA + sizeof(SlotRec) * (size_t)ANCH_PMAX * WAVE : 0);
+  }
+  // ---- fixed-anchor data (ANCH) ----
+  double *sh_anch;         // [ANCH_MAXA][4] pinned anchor positions
+  SlotRec *sh_prec;        // [ANCH_PMAX][64] pinned slot records (target + clamp bounds)
+  int aoff[ANCH ? ANCH_PMAX : 1];   // pinned slot -> row of sh_anch (double index)
+  int arot[K];             // (comp + q) % K: the tiles' rotation applied to an anchor row
+  const double *g_obs;     // [n_obs][4] obstacle centre + squared radius (global)
+  int n_obs;
+  bool obs_lane;           // this lane's node carries the obstacle hinges
+  __device__ inline void init_anchored(const uint32_t *pin_meta, const uint64_t obs_mask, const double *obs,
+                                       int n_obs_) {
+    sh_anch = sh_ck + 4 * WAVE;
+    sh_prec = reinterpret_cast<SlotRec *>(sh_anch + 4 * ANCH_MAXA);
+    g_obs = obs;
+    n_obs = n_obs_;
+    obs_lane = active && ((obs_mask >> node) & 1ull);
+#pragma unroll
+    for (int q = 0; q < K; ++q) arot[q] = (comp + q) % K;
+#pragma unroll
+    for (int s = 0; s < ANCH_PMAX; ++s) aoff[s] = (int)(pin_meta[s * WAVE + lane] & 0xffu) * 4;
+  }
+  // pinned slot records: anchor terms have template-constant targets
+  __device__ inline void load_pinned_records(const uint32_t *pin_meta, const double *pin_tgt) {
+    const float inf = __builtin_inff();
+#pragma unroll 1
+    for (int s = 0; s < ANCH_PMAX; ++s) {
+      const uint32_t m = pin_meta[s * WAVE + lane];
+      const int kind = (int)((m >> 8) & 3u);
+      SlotRec r;
+      r.tg = pin_tgt[s * WAVE + lane];
+      r.lo = (kind == GIK_TERM_EQ || kind == GIK_TERM_UPPER) ? -inf : 0.0f;
+      r.hi = (kind == GIK_TERM_EQ || kind == GIK_TERM_LOWER) ? inf : 0.0f;
+      sh_prec[s * WAVE + lane] = r;      // kind 0 (padding): clamp to (0, 0), inert
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   __device__ static inline SlotRec *rec_base(uint32_t *meta) {
     return reinterpret_cast<SlotRec *>(meta + MAXDEG * WAVE);
@@ -456,6 +505,31 @@ struct WaveCtx {
       f = fma(cl, cl, f);
       if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);  // bound the number of rows in flight
     }
+    if constexpr (ANCH) {
+      // point-to-anchor terms occur once (not from both ends): count them twice before the halving
+      double fa = 0.0;
+#pragma unroll 2
+      for (int s = 0; s < ANCH_PMAX; ++s) {
+        const SlotRec rc = sh_prec[s * WAVE + lane];
+        double d = 0.0;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          const double y = own.v[q] - sh_anch[aoff[s] + arot[q]];
+          d = fma(y, y, d);
+        }
+        const double cl = fmin(fmax(rc.tg - d, (double)rc.lo), (double)rc.hi);
+        fa = fma(cl, cl, fa);
+      }
+      const Row<K> nat = read_row(nat_off);
+      for (int k = 0; k < n_obs; ++k) {
+        const double4 o = *reinterpret_cast<const double4 *>(g_obs + 4 * k);   // wave-uniform
+        const double y0 = nat.v[0] - o.x, y1 = nat.v[1] - o.y, y2 = nat.v[K - 1] - o.z;
+        const double d = fma(y2, y2, fma(y1, y1, y0 * y0));
+        const double cl = obs_lane ? fmax(o.w - d, 0.0) : 0.0;
+        fa = fma(cl, cl, fa);
+      }
+      f = fma(2.0, fa, f);
+    }
     return 0.5 * wave_sum((active && comp == 0) ? f : 0.0);
   }
 
@@ -504,12 +578,58 @@ struct WaveCtx {
       G = fma(c, y[0], G);
       if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);  // bound the number of rows in flight
     }
+    double ba[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) ba[q] = 0.0;
+    if constexpr (ANCH) {
+      // point-to-anchor terms: the anchor does not move, so the term's Hessian block 2 a y y^T + c I
+      // goes to the node's diagonal block only (row c of it, rotated like bq)
+#pragma unroll 2
+      for (int s = 0; s < ANCH_PMAX; ++s) {
+        const SlotRec rc = sh_prec[s * WAVE + lane];
+        double y[K];
+        double d = 0.0;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          y[q] = own.v[q] - sh_anch[aoff[s] + arot[q]];
+          d = fma(y[q], y[q], d);
+        }
+        const double cl = fmin(fmax(rc.tg - d, (double)rc.lo), (double)rc.hi);
+        const bool act = (rc.lo * rc.hi < 0.0f) || (cl != 0.0);
+        const double c = -cl;
+        const double a2 = act ? 2.0 * y[0] : 0.0;
+#pragma unroll
+        for (int q = 0; q < K; ++q) ba[q] = fma(a2, y[q], ba[q]);
+        ba[0] += c;
+        G = fma(c, y[0], G);
+      }
+      const Row<K> nat = read_row(nat_off);
+      for (int k = 0; k < n_obs; ++k) {
+        const double4 o = *reinterpret_cast<const double4 *>(g_obs + 4 * k);   // wave-uniform
+        const double yn[3] = {nat.v[0] - o.x, nat.v[1] - o.y, nat.v[K - 1] - o.z};
+        const double d = fma(yn[2], yn[2], fma(yn[1], yn[1], yn[0] * yn[0]));
+        const double cl = obs_lane ? fmax(o.w - d, 0.0) : 0.0;
+        if (__builtin_amdgcn_ballot_w64(cl != 0.0) == 0ull) continue;   // nobody touches obstacle k
+        double y[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          const int r = arot[q];
+          y[q] = r == 0 ? yn[0] : (r == 1 ? yn[1] : yn[2]);
+        }
+        const double c = -cl;
+        const double a2 = (cl != 0.0) ? 2.0 * y[0] : 0.0;
+#pragma unroll
+        for (int q = 0; q < K; ++q) ba[q] = fma(a2, y[q], ba[q]);
+        ba[0] += c;
+        G = fma(c, y[0], G);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < K; ++q) {
       double t = 0.0;
 #pragma unroll
       for (int s = 0; s < MAXDEG; ++s) t += bq[s][q];
-      bsum[q] = t;                                     // ... and bsum = +2 sum_j B_ij
+      bsum[q] = fma(2.0, ba[q], t);                    // ... and bsum = +2 sum_j B_ij (+ anchors)
 #pragma unroll
       for (int s = 0; s < MAXDEG; ++s) bq[s][q] = -bq[s][q];
     }
@@ -571,6 +691,11 @@ struct WaveCtx {
   //          the right-hand side [0, 1, -1, 0]; Omega = c * u.  planar_proj_exact selects the
   //          mathematically intended matrix instead.
   __device__ inline void proj_setup(int planar_proj_exact) {
+    if constexpr (ANCH) {   // the anchors fix the gauge: no vertical space, proj = identity
+#pragma unroll
+      for (int m = 0; m < NC; ++m) Q[m] = pk[m] = pk2[m] = 0.0;
+      return;
+    }
     const Row<K> own = read_row(nat_off);  // natural component order (tile 0)
     const bool lead = active && comp == 0;
     if constexpr (K == 3) {
@@ -654,6 +779,7 @@ struct WaveCtx {
 
   // Z - Y Omega(Z)  (fixed_rank_psd_sym.py:111-113)
   __device__ inline double proj(double Z) const {
+    if constexpr (ANCH) return Z;
     double v[NC];
     if constexpr (K == 3) {
 #pragma unroll

@@ -74,7 +74,11 @@ class Template:
     """Goal-independent part of an IK problem family, resident on one GPU."""
 
     def __init__(self, N, k, term_i, term_j, term_kind, targets_static=None, device=None,
-                 params=None):
+                 params=None, anchored=None):
+        """anchored: None, or the fixed-anchor data of gik_anchored_desc as a dict (anchor_pos
+        [A,3], n_goal_anchor, term_target [T], pin_node / pin_anchor / pin_kind / pin_target,
+        obs [n_obs,4] (x, y, z, r^2), obs_node_mask [N], full_N, free_full_index,
+        anchor_full_index, axis_length) -- see include/graphik_amd.h."""
         self.lib = _ffi.lib()
         if not torch.cuda.is_available():
             raise _ffi.GikError("no HIP device visible: graphik_amd needs an AMD GPU (gfx950)")
@@ -114,8 +118,34 @@ class Template:
                                                    "cg_orth_value", "cg_beta_type")}
         self.params["solver"] = self.solver
         h = C.c_void_p()
+        self.anchored = anchored is not None
         with torch.cuda.device(self.device):
-            _ffi.check(self.lib.gik_template_create(C.byref(d), C.byref(h)))
+            if anchored is None:
+                _ffi.check(self.lib.gik_template_create(C.byref(d), C.byref(h)))
+            else:
+                ad, keep = _ffi.AnchoredDesc(), {}
+
+                def arr(name, dt):
+                    keep[name] = np.ascontiguousarray(anchored[name], dtype=dt)
+                    return keep[name].ctypes.data_as(C.POINTER(C.c_double if dt == np.float64 else C.c_int32))
+
+                ad.anchor_pos = arr("anchor_pos", np.float64)
+                ad.n_anchor = len(keep["anchor_pos"])
+                ad.n_goal_anchor = int(anchored["n_goal_anchor"])
+                ad.term_target = arr("term_target", np.float64)
+                assert len(keep["term_target"]) == self.T
+                ad.pin_node, ad.pin_anchor = arr("pin_node", np.int32), arr("pin_anchor", np.int32)
+                ad.pin_kind, ad.pin_target = arr("pin_kind", np.int32), arr("pin_target", np.float64)
+                ad.n_pin = len(keep["pin_node"])
+                ad.obs = arr("obs", np.float64)
+                ad.n_obs = len(keep["obs"])
+                ad.obs_node_mask = arr("obs_node_mask", np.int32)
+                ad.full_N = int(anchored["full_N"])
+                ad.free_full_index = arr("free_full_index", np.int32)
+                ad.anchor_full_index = arr("anchor_full_index", np.int32)
+                ad.axis_length = float(anchored["axis_length"])
+                self.n_goal_anchor, self.full_N = ad.n_goal_anchor, ad.full_N
+                _ffi.check(self.lib.gik_template_create_anchored(C.byref(d), C.byref(ad), C.byref(h)))
         self._h = h
         deg = np.bincount(np.concatenate([self.term_i, self.term_j]), minlength=self.N).max()
         self.maxdeg = next((m for m in ((9, 10, 20) if self.k == 3 else (6, 16, 31)) if m >= deg), int(deg))
@@ -161,7 +191,8 @@ class Template:
             t = t[None]
         if t.shape[0] == 1 and B > 1:
             t = t.expand(B, -1).contiguous()
-        assert t.shape == (B, self.T), (t.shape, (B, self.T))
+        width = self.T if not self.anchored else 3 * self.n_goal_anchor   # anchored: goal anchors
+        assert t.shape == (B, width), (t.shape, (B, width))
         return t
 
     # -- costgrd twins ------------------------------------------------------------------------
@@ -318,6 +349,28 @@ class Template:
                                              out["rot_err"].data_ptr(), self._stream()))
         res = {"x": out["Y"].reshape(B, self.N, self.k), "q": out["q"], "pos_err": out["pos_err"],
                "rot_err": out["rot_err"]}
+        res.update(_decode_stats(out["stats"]))
+        return res
+
+    def anchored_ik(self, base, T_goal):
+        """Whole pipeline through the fixed-anchor solve (gik_anchored_ik_batch): `base` is the
+        robot graph's Template (no obstacles) with its pipeline attached.  Returns device tensors:
+        x [B, full_N, 3] (all robot-graph nodes, anchors included), q, pos_err, rot_err + stats."""
+        assert self.anchored and base.has_pipeline
+        T, B = base._poses(T_goal)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        nws = int(self.lib.gik_anchored_ws_doubles(self._h, base._h, B))
+        ws = torch.empty(max(nws, 1), **f64)
+        out = {"Y": torch.empty(B, self.full_N * 3, **f64), "stats": _alloc_stats(B, self.device),
+               "q": torch.empty(B, base.n_joints, **f64), "pos_err": torch.empty(B, **f64),
+               "rot_err": torch.empty(B, **f64)}
+        with torch.cuda.device(self.device):
+            _ffi.check(self.lib.gik_anchored_ik_batch(self._h, base._h, T.data_ptr(), B, ws.data_ptr(),
+                                                      out["Y"].data_ptr(), out["stats"].data_ptr(),
+                                                      out["q"].data_ptr(), out["pos_err"].data_ptr(),
+                                                      out["rot_err"].data_ptr(), self._stream()))
+        res = {"x": out["Y"].reshape(B, self.full_N, 3), "q": out["q"], "pos_err": out["pos_err"],
+               "rot_err": out["rot_err"], "_ws": ws}
         res.update(_decode_stats(out["stats"]))
         return res
 

@@ -298,6 +298,92 @@ class BatchProblem:
         return pos, rot
 
 
+class AnchoredProblem:
+    """Opt-in "intended" obstacle semantics.  graph_base.py:182-211 ties every
+    node with a known position -- base frame, goal nodes, obstacle centres -- to the others by
+    equality edges and means to add robot<->obstacle lower-bound hinges (:205-211; the TYPE
+    comparison at :207 never fires, so the reference creates none, and that observable behaviour
+    stays the default everywhere else in this package).  Here those nodes are CONSTANTS instead of
+    rows of Y and the hinges exist: UR10 + table_environment() becomes a 10-node problem with 100
+    point-to-obstacle hinges per p-node on the wavefront kernel, instead of N = 116 / 5612 terms on
+    the workgroup kernel.  The anchors fix the gauge, so the search space is Euclidean.
+
+    graph: a ProblemGraphRevolute (chain) with its obstacles added (either spelling of
+    add_spherical_obstacle).  The initial point is the robot graph's own (bound smoothing + MDS
+    without obstacles) fitted to the world frame by its anchors."""
+
+    def __init__(self, graph, params=None, device=None):
+        import copy
+        from ..utils.constants import OBSTACLE, ROBOT, TYPE, MAIN_PREFIX
+        from .. import _ffi
+        if graph.dim != 3 or not graph.robot.is_chain:
+            raise NotImplementedError("the fixed-anchor formulation covers 3-D chains")
+        self.graph, self.robot = graph, graph.robot
+        obstacles = [n for n in graph.node_ids if graph.nodes[n].get(TYPE) == OBSTACLE]
+        bare = copy.deepcopy(graph)
+        bare.clear_obstacles()
+        self.base = BatchProblem(bare, use_limits=True, params=params, device=device)
+        if not self.base.device_pipeline:
+            raise NotImplementedError("robot graph beyond the device pipeline")
+        bp = self.base
+        N = bp.N
+        goal = list(bp.goal_nodes)
+        anchors = list(bp.anchor_nodes) + goal               # constant rows first, goal rows last
+        free = [i for i in range(N) if i not in anchors]
+        fidx = {n: f for f, n in enumerate(free)}
+        om, pL, pU, D = bp.omega, bp.psi_L, bp.psi_U, bp.base_D
+        sub = np.ix_(free, free)
+        ti, tj, tk, tv = build_terms(om[sub], pL[sub], pU[sub], True)
+        Dff = D[sub]
+        target = np.where(np.isnan(tv), Dff[ti, tj], tv)
+        pin = []
+        for i in free:
+            for r, a in enumerate(anchors):
+                if om[i, a] != 0:
+                    pin.append((fidx[i], r, _ffi.TERM_EQ, D[i, a]))
+                if pL[i, a] != 0:
+                    pin.append((fidx[i], r, _ffi.TERM_LOWER, pL[i, a]))
+                if pU[i, a] != 0:
+                    pin.append((fidx[i], r, _ffi.TERM_UPPER, pU[i, a]))
+        self.obstacles = np.array([[*np.asarray(graph.nodes[o]["pos"], dtype=float), float(graph.nodes[o]["radius"])]
+                                   for o in obstacles], dtype=float).reshape(-1, 4)
+        obs = self.obstacles.copy()
+        obs[:, 3] = obs[:, 3] ** 2                            # LOWER = radius  ->  psi_L = radius^2
+        names = [bare.node_ids[i] for i in free]
+        mask = [int(n[0] == MAIN_PREFIX and ROBOT in bare.nodes[n].get(TYPE, [])) for n in names]
+        pos = np.zeros((len(anchors), 3))
+        pos[:len(bp.anchor_nodes)] = bp.anchor_pos
+        self.free, self.anchors, self.pin = free, anchors, pin
+        self.free_terms = (ti, tj, tk, target)
+        self.obs_mask = np.array(mask, dtype=np.int32)
+        self.template = Template(
+            len(free), 3, ti, tj, tk, None, device=device, params=params,
+            anchored=dict(anchor_pos=pos, n_goal_anchor=len(goal), term_target=target,
+                          pin_node=[p[0] for p in pin], pin_anchor=[p[1] for p in pin],
+                          pin_kind=[p[2] for p in pin], pin_target=[p[3] for p in pin],
+                          obs=obs, obs_node_mask=mask, full_N=N, free_full_index=free,
+                          anchor_full_index=anchors, axis_length=graph.axis_length))
+
+    def goal_anchors(self, T_goals):
+        """[B,4,4] -> [B, 2*3]: p_n, q_n world positions (graph_revolute.py:243-249)."""
+        return self.base.goal_positions(T_goals).reshape(len(T_goals), -1)
+
+    def solve(self, T_goals):
+        """Goal poses -> dict of device tensors (x [B, N_robot, 3], q, pos_err, rot_err, stats)."""
+        return self.template.anchored_ik(self.base.template, np.asarray(T_goals, dtype=float))
+
+    def clearance(self, Y_full, include_goal=False):
+        """min over (p-node of the robot, obstacle) of |p - centre| - radius per goal (>= 0:
+        collision free in the sense of graph_base.py:205-211).  Y_full [B, N_robot, 3] (numpy).
+        The end effector p_n sits where the goal puts it (a constant of the problem), so it only
+        counts with include_goal=True."""
+        g = self.base.graph
+        pn = [g.index(f"p{i}") for i in range(1, self.robot.n + (1 if include_goal else 0))]
+        P = np.asarray(Y_full)[:, pn]                                            # [B, n, 3]
+        d = np.linalg.norm(P[:, :, None, :] - self.obstacles[None, None, :, :3], axis=-1)
+        return (d - self.obstacles[None, None, :, 3]).min(axis=(1, 2))
+
+
 # BatchProblem objects (device handles) of recent solve_batch / solve_with_riemannian calls.  The
 # reference re-reads the graph on every call (riemannian_solver.py:220-234), so the key is the
 # CONTENT a BatchProblem is built from -- edge pattern, distances, limits, anchor positions, robot

@@ -223,6 +223,57 @@ int gik_ik_batch(const gik_template *t, const double *d_T_goal, int B, double *d
                  double *d_Y, gik_stats *d_stats, double *d_q, double *d_pos_err,
                  double *d_rot_err, void *stream);
 
+/* ---- fixed-anchor formulation: "intended" obstacle semantics (opt-in) -----------------------
+ * graph_base.py:182-211 ties every node with a known position (base frame, goal nodes, obstacle
+ * centres) to the others by equality edges and MEANS to add robot<->obstacle lower-bound hinges
+ * (:205-211; the TYPE comparison at :207 never fires, so the reference creates none -- that
+ * observable behaviour stays the default of this library).  Here those nodes are constants
+ * instead of rows of Y, and the hinges exist: UR10 + table_environment() is a 10-node problem with
+ * 100 point-to-obstacle hinges per p-node instead of N = 116 / 5612 terms.  The free nodes are the
+ * template's N nodes; its terms are the free-free terms (targets are template constants:
+ * `term_target`).  With an anchored template
+ *   - gik_solve_batch's `d_targets` argument carries the per-problem goal anchors [B][n_goal*3],
+ *     and so does the `d_targets` argument of gik_cost / gik_grad / gik_cost_and_grad / gik_hess;
+ *   - gik_proj is the identity (the anchors fix the gauge; the search space is Euclidean).     */
+typedef struct {
+  int32_t n_anchor;              /* rows of the pinned-anchor table (<= 16): base + goal anchors */
+  int32_t n_goal_anchor;         /* the LAST n_goal_anchor rows are per-problem (goal nodes)     */
+  const double *anchor_pos;      /* [n_anchor][3] world positions (goal rows ignored)            */
+  const double *term_target;     /* [T] squared targets of the template's (free-free) terms      */
+  int32_t n_pin;                 /* point-to-anchor terms, at most 8 per free node               */
+  const int32_t *pin_node;       /* [n_pin] free node                                            */
+  const int32_t *pin_anchor;     /* [n_pin] anchor row                                           */
+  const int32_t *pin_kind;       /* [n_pin] GIK_TERM_*                                           */
+  const double *pin_target;      /* [n_pin] squared distance / psi_L / psi_U                     */
+  int32_t n_obs;                 /* spherical obstacles                                          */
+  int32_t reserved0;
+  const double *obs;             /* [n_obs][4] centre x, y, z and SQUARED radius                 */
+  const int32_t *obs_node_mask;  /* [N] 1: the free node keeps |Y_i - centre| >= radius          */
+  /* mapping to the robot graph (gik_anchored_ik_batch) */
+  int32_t full_N;                /* nodes of the robot graph                                     */
+  int32_t reserved1;
+  const int32_t *free_full_index;    /* [N]                                                      */
+  const int32_t *anchor_full_index;  /* [n_anchor]; goal rows: p_n then q_n                      */
+  double axis_length;
+} gik_anchored_desc;
+
+int gik_template_create_anchored(const gik_template_desc *desc, const gik_anchored_desc *adesc,
+                                 gik_template **out);
+
+/* goal poses -> joint angles through the anchored solve, one stream, no host round trip:
+ * gik_prepare_batch on `base` (the robot graph WITHOUT obstacles, pipeline attached: bound
+ * smoothing + MDS initial point) -> orthogonal Procrustes fit of that point's anchor rows onto the
+ * world frame -> anchored trust-region solve -> full point matrix d_Y_full [B][full_N*3] ->
+ * gik_recover_batch on `base`.  d_ws: scratch of gik_anchored_ws_doubles(anch, base, B) doubles. */
+size_t gik_anchored_ws_doubles(const gik_template *anch, const gik_template *base, int B);
+int gik_anchored_ik_batch(const gik_template *anch, const gik_template *base, const double *d_T_goal,
+                          int B, double *d_ws, double *d_Y_full, gik_stats *d_stats, double *d_q,
+                          double *d_pos_err, double *d_rot_err, void *stream);
+
+/* Duration (ms, HIP events on the call's stream) of the anchored solve kernel inside the most
+ * recent gik_anchored_ik_batch on this handle; waits for it.  < 0 if there was none.           */
+double gik_anchored_last_solve_ms(const gik_template *anch);
+
 #ifdef __cplusplus
 }
 #endif

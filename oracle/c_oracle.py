@@ -47,6 +47,11 @@ class CgTraj(C.Structure):
                 ("costevals", C.POINTER(C.c_int))]
 
 
+class AnchorTerms(C.Structure):
+    _fields_ = [("n", C.c_int), ("node", C.POINTER(C.c_int)), ("pos", C.POINTER(C.c_double)),
+                ("target", C.POINTER(C.c_double)), ("kind", C.POINTER(C.c_int))]
+
+
 def build(force=False):
     """Compile oracle/_build/*.so with gcc (idempotent)."""
     so = os.path.join(_HERE, "_build", "libgik_oracle.so")
@@ -84,6 +89,9 @@ def lib(fast=False):
         L.gik_o_rtr_solve.argtypes = [_dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int64, C.c_int,
                                       C.c_int, C.POINTER(Params), C.POINTER(Result),
                                       C.POINTER(Traj)]
+        L.gik_o_rtr_solve_anchored.argtypes = [_dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int64, C.c_int,
+                                               C.c_int, C.POINTER(AnchorTerms), C.POINTER(Params),
+                                               C.POINTER(Result), C.POINTER(Traj)]
         L.gik_o_cg_default_params.argtypes = [C.POINTER(CgParams)]
         L.gik_o_cg_solve.argtypes = [_dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int64, C.c_int, C.c_int,
                                      C.POINTER(CgParams), C.POINTER(Result), C.POINTER(CgTraj)]
@@ -251,6 +259,42 @@ def rtr_solve_batch(Y_init, D_goal, omega, psi_L, psi_U, use_limits=True, nthrea
            "iterations": np.array([r.iterations for r in res]),
            "inner_total": np.array([r.inner_total for r in res])}
     return out
+
+
+def rtr_solve_anchored(Y_init, D_ff, omega_ff, psi_L_ff, psi_U_ff, at_node, at_pos, at_target, at_kind,
+                       traj_cap=0, **kw):
+    """Trust-region solve of the fixed-anchor formulation (gik_o_rtr_solve_anchored): Y_init
+    [Nf,3] free nodes, dense free-free matrices, point-to-anchor terms (node, position, squared
+    target, kind)."""
+    Y = _c(Y_init).copy()
+    N, k = Y.shape
+    omega, psi_L, psi_U = _c(omega_ff), _c(psi_L_ff), _c(psi_U_ff)
+    ii, jj = _inds(limit_inds(omega, psi_L, psi_U))
+    p = default_params(use_limits=1, **kw)
+    node = np.ascontiguousarray(at_node, dtype=np.int32)
+    pos = np.ascontiguousarray(at_pos, dtype=np.float64)
+    tgt = np.ascontiguousarray(at_target, dtype=np.float64)
+    kind = np.ascontiguousarray(at_kind, dtype=np.int32)
+    at = AnchorTerms(len(node), node.ctypes.data_as(C.POINTER(C.c_int)), pos.ctypes.data_as(C.POINTER(C.c_double)),
+                     tgt.ctypes.data_as(C.POINTER(C.c_double)), kind.ctypes.data_as(C.POINTER(C.c_int)))
+    res = Result()
+    tr, keep = None, {}
+    if traj_cap > 0:
+        tr = Traj()
+        tr.cap = traj_cap
+        for name, ct, dt in (("Delta", C.c_double, np.float64), ("numit", C.c_int, np.int32),
+                             ("stop", C.c_int, np.int32), ("f_before", C.c_double, np.float64),
+                             ("gradnorm_after", C.c_double, np.float64), ("accept", C.c_int, np.int32)):
+            keep[name] = np.zeros(traj_cap, dtype=dt)
+            setattr(tr, name, keep[name].ctypes.data_as(C.POINTER(ct)))
+    rc = lib().gik_o_rtr_solve_anchored(Y, _c(D_ff), omega, psi_L, psi_U, ii, jj, len(ii), N, k, C.byref(at),
+                                        C.byref(p), C.byref(res), C.byref(tr) if tr else None)
+    assert rc == 0
+    info = {"x": Y, "f(x)": res.f, "gradnorm": res.gradnorm, "iterations": res.iterations,
+            "inner_total": res.inner_total, "stop": res.stop}
+    if tr:
+        info["traj"] = {k_: v[: tr.len] for k_, v in keep.items()}
+    return info
 
 
 def cg_solve(Y_init, D_goal, omega, psi_L=None, psi_U=None, use_limits=True, traj_cap=0, **kw):

@@ -375,14 +375,66 @@ typedef struct {
   int64_t n_inds;
   int N, k, use_limits;
   double *tmp; /* N*k scratch for ehess before projection */
+  /* fixed-anchor variant (gik_o_rtr_solve_anchored): point-to-anchor terms, no quotient */
+  const gik_o_anchor_terms *at;
 } ctx_t;
+
+/* point-to-anchor residual terms ("intended" obstacle semantics with anchors as
+ * constants): same residuals as costs.py:80-93 with Y_j replaced by a fixed position:
+ *   kind 1: (target - d)^2    kind 2: max(target - d, 0)^2    kind 3: max(d - target, 0)^2 */
+static double anch_cost(const gik_o_anchor_terms *at, const double *Y, int k) {
+  double f = 0.0;
+  for (int t = 0; t < at->n; ++t) {
+    double d = 0.0;
+    for (int c = 0; c < k; ++c) {
+      const double y = Y[at->node[t] * k + c] - at->pos[t * 3 + c];
+      d += y * y;
+    }
+    double u = at->target[t] - d;
+    if (at->kind[t] == 2) u = u > 0 ? u : 0.0;
+    if (at->kind[t] == 3) u = u < 0 ? u : 0.0;
+    f += u * u;
+  }
+  return f;
+}
+static void anch_grad(const gik_o_anchor_terms *at, const double *Y, int k, double *g) {
+  for (int t = 0; t < at->n; ++t) {
+    double y[3] = {0, 0, 0}, d = 0.0;
+    for (int c = 0; c < k; ++c) {
+      y[c] = Y[at->node[t] * k + c] - at->pos[t * 3 + c];
+      d += y[c] * y[c];
+    }
+    double cc = d - at->target[t];                 /* egrad = 1/2 grad f, like costs.py:98-123 */
+    if (at->kind[t] == 2 && !(at->target[t] - d > 0)) cc = 0.0;
+    if (at->kind[t] == 3 && !(d - at->target[t] > 0)) cc = 0.0;
+    for (int c = 0; c < k; ++c) g[at->node[t] * k + c] += 2 * cc * y[c];
+  }
+}
+static void anch_hess(const gik_o_anchor_terms *at, const double *Y, const double *w, int k, double *h) {
+  for (int t = 0; t < at->n; ++t) {
+    double y[3] = {0, 0, 0}, d = 0.0, s = 0.0;
+    for (int c = 0; c < k; ++c) {
+      y[c] = Y[at->node[t] * k + c] - at->pos[t * 3 + c];
+      d += y[c] * y[c];
+      s += y[c] * w[at->node[t] * k + c];
+    }
+    int act = 1;
+    if (at->kind[t] == 2) act = at->target[t] - d > 0;
+    if (at->kind[t] == 3) act = d - at->target[t] > 0;
+    if (!act) continue;
+    const double cc = d - at->target[t];           /* costs.py:175-207 with w_j = 0 */
+    for (int c = 0; c < k; ++c)
+      h[at->node[t] * k + c] += 2 * (2 * s * y[c] + cc * w[at->node[t] * k + c]);
+  }
+}
 
 static double ctx_cost(const ctx_t *c, const double *Y) {
   /* riemannian_solver.py:84-85 (K * jcost) / :131-132 (K * lcost), K = 1 */
   if (c->use_limits)
     return gik_o_lcost(Y, c->D_goal, c->omega, c->psi_L, c->psi_U, c->ii, c->jj, c->n_inds, c->N,
-                       c->k);
-  return gik_o_jcost(Y, c->D_goal, c->ii, c->jj, c->n_inds, c->N, c->k);
+                       c->k) + (c->at ? anch_cost(c->at, Y, c->k) : 0.0);
+  return gik_o_jcost(Y, c->D_goal, c->ii, c->jj, c->n_inds, c->N, c->k) +
+         (c->at ? anch_cost(c->at, Y, c->k) : 0.0);
 }
 
 static void ctx_grad(const ctx_t *c, const double *Y, double *g) {
@@ -392,6 +444,7 @@ static void ctx_grad(const ctx_t *c, const double *Y, double *g) {
                 g);
   else
     gik_o_jgrad(Y, c->D_goal, c->ii, c->jj, c->n_inds, c->N, c->k, g);
+  if (c->at) anch_grad(c->at, Y, c->k, g);
 }
 
 static void ctx_hess(const ctx_t *c, const double *Y, const double *w, double *out) {
@@ -402,6 +455,11 @@ static void ctx_hess(const ctx_t *c, const double *Y, const double *w, double *o
                 c->k, c->tmp);
   else
     gik_o_jhess(Y, w, c->D_goal, c->ii, c->jj, c->n_inds, c->N, c->k, c->tmp);
+  if (c->at) { /* anchors fix the gauge: Euclidean space, no horizontal projection */
+    anch_hess(c->at, Y, w, c->k, c->tmp);
+    for (int t = 0; t < c->N * c->k; ++t) out[t] = c->tmp[t];
+    return;
+  }
   gik_o_proj(Y, c->tmp, c->N, c->k, out);
 }
 
@@ -513,12 +571,21 @@ static int tcg(const ctx_t *c, const double *x, const double *fgradx, double *et
 int gik_o_rtr_solve(double *Y, const double *D_goal, const double *omega, const double *psi_L,
                     const double *psi_U, const int64_t *ii, const int64_t *jj, int64_t n_inds,
                     int N, int k, const gik_o_params *p, gik_o_result *res, gik_o_traj *traj) {
+  return gik_o_rtr_solve_anchored(Y, D_goal, omega, psi_L, psi_U, ii, jj, n_inds, N, k, 0, p, res, traj);
+}
+
+/* The same trust-region solver on the fixed-anchor formulation: Y holds the FREE nodes only, `at`
+ * the point-to-anchor terms; the metric is Euclidean (at == NULL: the reference's quotient). */
+int gik_o_rtr_solve_anchored(double *Y, const double *D_goal, const double *omega, const double *psi_L,
+                             const double *psi_U, const int64_t *ii, const int64_t *jj, int64_t n_inds,
+                             int N, int k, const gik_o_anchor_terms *at, const gik_o_params *p,
+                             gik_o_result *res, gik_o_traj *traj) {
   const int n = N * k;
   double *buf = (double *)malloc(sizeof(double) * (size_t)n * 10);
   if (!buf) return -1;
   double *fgradx = buf, *eta = buf + n, *Heta = buf + 2 * n, *x_prop = buf + 3 * n,
          *work = buf + 4 * n, *tmp = buf + 9 * n;
-  ctx_t c = {D_goal, omega, psi_L, psi_U, ii, jj, n_inds, N, k, p->use_limits, tmp};
+  ctx_t c = {D_goal, omega, psi_L, psi_U, ii, jj, n_inds, N, k, p->use_limits, tmp, at};
   double *x = Y;
 
   const double Delta_bar = 10.0 + k;     /* :128-131 typicaldist (fixed_rank_psd_sym.py:71-73) */
@@ -644,7 +711,7 @@ int gik_o_cg_solve(double *Y, const double *D_goal, const double *omega, const d
   double *grad = buf, *desc = buf + n, *newx = buf + 2 * n, *newgrad = buf + 3 * n,
          *oldgrad = buf + 4 * n, *tdesc = buf + 5 * n, *diff = buf + 6 * n, *tmp = buf + 7 * n,
          *trial = buf + 8 * n;
-  ctx_t c = {D_goal, omega, psi_L, psi_U, ii, jj, n_inds, N, k, p->use_limits, tmp};
+  ctx_t c = {D_goal, omega, psi_L, psi_U, ii, jj, n_inds, N, k, p->use_limits, tmp, 0};
   double *x = Y;
   int iter = 0, stop = 1, costevals_total = 0;
   double stepsize = NAN;

@@ -88,6 +88,23 @@ int gik_o_rtr_solve(double *Y, const double *D_goal, const double *omega, const 
                     const double *psi_U, const int64_t *ii, const int64_t *jj, int64_t n_inds,
                     int N, int k, const gik_o_params *p, gik_o_result *res, gik_o_traj *traj);
 
+/* Fixed-anchor formulation (opt-in "intended" obstacle semantics): nodes with a
+ * known position are constants, not rows of Y, and the robot<->obstacle lower-bound hinges that
+ * graph_base.py:205-211 means to create exist.  n point-to-anchor terms: free node index, anchor
+ * position, squared target, kind (1 equality, 2 lower hinge, 3 upper hinge).  No reference
+ * counterpart to pin it to: it is the twin the HIP anchored kernels are tested against.        */
+typedef struct {
+  int n;
+  const int *node;        /* [n] */
+  const double *pos;      /* [n][3] */
+  const double *target;   /* [n] */
+  const int *kind;        /* [n] */
+} gik_o_anchor_terms;
+int gik_o_rtr_solve_anchored(double *Y, const double *D_goal, const double *omega, const double *psi_L,
+                             const double *psi_U, const int64_t *ii, const int64_t *jj, int64_t n_inds,
+                             int N, int k, const gik_o_anchor_terms *at, const gik_o_params *p,
+                             gik_o_result *res, gik_o_traj *traj);
+
 /* Batch driver (OpenMP over problems) -- used as bench.py's cpu_baseline.  D_goal is per
  * problem (B x N x N); omega/psi shared.  Y: B x N x k in/out.                           */
 int gik_o_rtr_solve_batch(double *Y, const double *D_goal, const double *omega,
