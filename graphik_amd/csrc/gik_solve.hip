@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
   if constexpr (ANCH) {
     // every target is a template constant here: records, pinned records and the constant rows of
     // the anchor table are staged once per wave; only the goal anchors change per problem
-    cx.init_anchored(a.an.pin_meta, a.an.obs_mask, a.an.obs, a.an.n_obs);
+    cx.init_anchored(a.an.obs_mask, a.an.obs, a.an.n_obs);
     for (int t = lane; t < a.T; t += WAVE) sh_tgt[t] = a.targets[t];
     for (int t = lane; t < 4 * ANCH_MAXA; t += WAVE) cx.sh_anch[t] = a.an.anch_const[t];
     __builtin_amdgcn_wave_barrier();
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
   Ctx cx;
   cx.init(lane, a.N, sh_tiles, sh_tgt, sh_meta);
   if constexpr (ANCH) {
-    cx.init_anchored(a.an.pin_meta, a.an.obs_mask, a.an.obs, a.an.n_obs);
+    cx.init_anchored(a.an.obs_mask, a.an.obs, a.an.n_obs);
     for (int t = lane; t < 4 * ANCH_MAXA; t += WAVE) cx.sh_anch[t] = a.an.anch_const[t];
     __builtin_amdgcn_wave_barrier();
     if (lane < 3 * a.an.n_goal)
@@ -838,6 +838,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
       return fail("anchored templates: k = 3, TrustRegions, theta = 1, wavefront path");
     if (ad->n_anchor < 1 || ad->n_anchor > ANCH_MAXA || ad->n_goal_anchor < 0 || ad->n_goal_anchor > ad->n_anchor)
       return fail("anchored templates: 1 <= n_anchor <= 16, goal anchors are the last rows");
+    if (ad->n_obs > ANCH_MAXOBS) return fail("anchored templates: at most 128 obstacles");
     if (ad->n_obs < 0 || ad->n_pin < 0 || d->N > 63 || !ad->term_target || !ad->free_full_index ||
         !ad->anchor_full_index || !ad->anchor_pos)
       return fail("anchored templates: bad descriptor");

@@ -320,6 +320,7 @@ struct Row {
 // fix the gauge: the search space is Euclidean (no horizontal projection, Q = 0).
 constexpr int ANCH_PMAX = 8;
 constexpr int ANCH_MAXA = 16;   // rows of the pinned-anchor table
+constexpr int ANCH_MAXOBS = 128; // obstacles (staged in LDS: 32 B each)
 
 template <int K, int MAXDEG, bool ANCH = false>
 struct WaveCtx {
@@ -342,42 +343,61 @@ struct WaveCtx {
     return sizeof(double) * ((size_t)K * TILE + (size_t)((T + 1) & ~1)) +
            sizeof(uint32_t) * (size_t)MAXDEG * WAVE + sizeof(SlotRec) * (size_t)MAXDEG * WAVE +
            (HAS_CK ? sizeof(double) * 4 * WAVE : 0) +
-           (ANCH ? sizeof(double) * 4 * ANCH_MAXA + sizeof(SlotRec) * (size_t)ANCH_PMAX * WAVE : 0);
+           (ANCH ? sizeof(double) * 4 * (ANCH_MAXA + ANCH_MAXOBS) + 16 * (size_t)ANCH_PMAX * WAVE : 0);
   }
   // ---- fixed-anchor data (ANCH) ----
+  // Everything per lane lives in LDS records (the 9-slot kernel has no VGPR to spare: per-lane
+  // offset tables in registers pushed it into scratch, measured 9 GB of spill traffic per launch).
+  struct PinRec {
+    double tg;        // squared target
+    uint32_t meta;    // [7:0] anchor row, [9:8] kind (0 = padding, inert)
+    uint32_t pad;
+  };
   double *sh_anch;         // [ANCH_MAXA][4] pinned anchor positions
-  SlotRec *sh_prec;        // [ANCH_PMAX][64] pinned slot records (target + clamp bounds)
-  int aoff[ANCH ? ANCH_PMAX : 1];   // pinned slot -> row of sh_anch (double index)
-  int arot[K];             // (comp + q) % K: the tiles' rotation applied to an anchor row
-  const double *g_obs;     // [n_obs][4] obstacle centre + squared radius (global)
+  PinRec *sh_prec;         // [ANCH_PMAX][64] pinned slot records
+  // Obstacle centres + squared radii, staged in LDS once per wave and read at a wave-uniform
+  // address (broadcast).  Read straight from global memory the two obstacle loops cost a
+  // dependent ~400-cycle round trip per obstacle (the compiler emits vector loads for the uniform
+  // address): 80 k cycles per outer iteration, more than its truncated-CG solve.
+  double *sh_obs;          // [ANCH_MAXOBS][4]
   int n_obs;
   bool obs_lane;           // this lane's node carries the obstacle hinges
-  __device__ inline void init_anchored(const uint32_t *pin_meta, const uint64_t obs_mask, const double *obs,
-                                       int n_obs_) {
+  __device__ inline void init_anchored(const uint64_t obs_mask, const double *obs, int n_obs_) {
     sh_anch = sh_ck + 4 * WAVE;
-    sh_prec = reinterpret_cast<SlotRec *>(sh_anch + 4 * ANCH_MAXA);
-    g_obs = obs;
+    sh_obs = sh_anch + 4 * ANCH_MAXA;
+    sh_prec = reinterpret_cast<PinRec *>(sh_obs + 4 * ANCH_MAXOBS);
     n_obs = n_obs_;
     obs_lane = active && ((obs_mask >> node) & 1ull);
-#pragma unroll
-    for (int q = 0; q < K; ++q) arot[q] = (comp + q) % K;
-#pragma unroll
-    for (int s = 0; s < ANCH_PMAX; ++s) aoff[s] = (int)(pin_meta[s * WAVE + lane] & 0xffu) * 4;
+    for (int t = lane; t < 4 * n_obs_; t += WAVE) sh_obs[t] = obs[t];
+    __builtin_amdgcn_wave_barrier();
   }
   // pinned slot records: anchor terms have template-constant targets
   __device__ inline void load_pinned_records(const uint32_t *pin_meta, const double *pin_tgt) {
-    const float inf = __builtin_inff();
 #pragma unroll 1
     for (int s = 0; s < ANCH_PMAX; ++s) {
-      const uint32_t m = pin_meta[s * WAVE + lane];
-      const int kind = (int)((m >> 8) & 3u);
-      SlotRec r;
+      PinRec r;
       r.tg = pin_tgt[s * WAVE + lane];
-      r.lo = (kind == GIK_TERM_EQ || kind == GIK_TERM_UPPER) ? -inf : 0.0f;
-      r.hi = (kind == GIK_TERM_EQ || kind == GIK_TERM_LOWER) ? inf : 0.0f;
-      sh_prec[s * WAVE + lane] = r;      // kind 0 (padding): clamp to (0, 0), inert
+      r.meta = pin_meta[s * WAVE + lane];
+      r.pad = 0;
+      sh_prec[s * WAVE + lane] = r;
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  // clamped residual of a point-to-anchor term from its squared distance: clamp(tg - d, lo, hi) with
+  // the kind's bounds (see SlotRec); `eq` returns whether the term is an equality
+  __device__ static inline double pin_residual(double tg, int kind, double d, bool &eq) {
+    const double u = tg - d;
+    eq = kind == GIK_TERM_EQ;
+    const double lo = (kind == GIK_TERM_EQ || kind == GIK_TERM_UPPER) ? -__builtin_inf() : 0.0;
+    const double hi = (kind == GIK_TERM_EQ || kind == GIK_TERM_LOWER) ? __builtin_inf() : 0.0;
+    return fmin(fmax(u, lo), hi);
+  }
+  // this lane's rotated view (y_c, y_c+1, y_c+2) of a natural-order 3-vector
+  __device__ inline void rotate_nat(const double (&yn)[3], double (&y)[K]) const {
+    static_assert(!ANCH || K == 3, "");
+    y[0] = comp == 0 ? yn[0] : (comp == 1 ? yn[1] : yn[2]);
+    y[1] = comp == 0 ? yn[1] : (comp == 1 ? yn[2] : yn[0]);
+    y[K - 1] = comp == 0 ? yn[2] : (comp == 1 ? yn[0] : yn[1]);
   }
   __device__ static inline SlotRec *rec_base(uint32_t *meta) {
     return reinterpret_cast<SlotRec *>(meta + MAXDEG * WAVE);
@@ -508,21 +528,20 @@ struct WaveCtx {
     if constexpr (ANCH) {
       // point-to-anchor terms occur once (not from both ends): count them twice before the halving
       double fa = 0.0;
-#pragma unroll 2
+      const Row<K> nat = read_row(nat_off);
+#pragma unroll 1
       for (int s = 0; s < ANCH_PMAX; ++s) {
-        const SlotRec rc = sh_prec[s * WAVE + lane];
-        double d = 0.0;
-#pragma unroll
-        for (int q = 0; q < K; ++q) {
-          const double y = own.v[q] - sh_anch[aoff[s] + arot[q]];
-          d = fma(y, y, d);
-        }
-        const double cl = fmin(fmax(rc.tg - d, (double)rc.lo), (double)rc.hi);
+        const PinRec rc = sh_prec[s * WAVE + lane];
+        const double *a = sh_anch + (rc.meta & 0xffu) * 4;
+        const double y0 = nat.v[0] - a[0], y1 = nat.v[1] - a[1], y2 = nat.v[K - 1] - a[2];
+        const double d = fma(y2, y2, fma(y1, y1, y0 * y0));
+        bool eq;
+        const double cl = pin_residual(rc.tg, (int)((rc.meta >> 8) & 3u), d, eq);
         fa = fma(cl, cl, fa);
       }
-      const Row<K> nat = read_row(nat_off);
+#pragma unroll 4
       for (int k = 0; k < n_obs; ++k) {
-        const double4 o = *reinterpret_cast<const double4 *>(g_obs + 4 * k);   // wave-uniform
+        const double4 o = *reinterpret_cast<const double4 *>(sh_obs + 4 * k);   // wave-uniform
         const double y0 = nat.v[0] - o.x, y1 = nat.v[1] - o.y, y2 = nat.v[K - 1] - o.z;
         const double d = fma(y2, y2, fma(y1, y1, y0 * y0));
         const double cl = obs_lane ? fmax(o.w - d, 0.0) : 0.0;
@@ -584,18 +603,18 @@ struct WaveCtx {
     if constexpr (ANCH) {
       // point-to-anchor terms: the anchor does not move, so the term's Hessian block 2 a y y^T + c I
       // goes to the node's diagonal block only (row c of it, rotated like bq)
-#pragma unroll 2
+      const Row<K> nat = read_row(nat_off);
+#pragma unroll 1
       for (int s = 0; s < ANCH_PMAX; ++s) {
-        const SlotRec rc = sh_prec[s * WAVE + lane];
+        const PinRec rc = sh_prec[s * WAVE + lane];
+        const double *a = sh_anch + (rc.meta & 0xffu) * 4;
+        const double yn[3] = {nat.v[0] - a[0], nat.v[1] - a[1], nat.v[K - 1] - a[2]};
+        const double d = fma(yn[2], yn[2], fma(yn[1], yn[1], yn[0] * yn[0]));
+        bool eq;
+        const double cl = pin_residual(rc.tg, (int)((rc.meta >> 8) & 3u), d, eq);
         double y[K];
-        double d = 0.0;
-#pragma unroll
-        for (int q = 0; q < K; ++q) {
-          y[q] = own.v[q] - sh_anch[aoff[s] + arot[q]];
-          d = fma(y[q], y[q], d);
-        }
-        const double cl = fmin(fmax(rc.tg - d, (double)rc.lo), (double)rc.hi);
-        const bool act = (rc.lo * rc.hi < 0.0f) || (cl != 0.0);
+        rotate_nat(yn, y);
+        const bool act = eq || (cl != 0.0);
         const double c = -cl;
         const double a2 = act ? 2.0 * y[0] : 0.0;
 #pragma unroll
@@ -603,19 +622,15 @@ struct WaveCtx {
         ba[0] += c;
         G = fma(c, y[0], G);
       }
-      const Row<K> nat = read_row(nat_off);
+#pragma unroll 4
       for (int k = 0; k < n_obs; ++k) {
-        const double4 o = *reinterpret_cast<const double4 *>(g_obs + 4 * k);   // wave-uniform
+        const double4 o = *reinterpret_cast<const double4 *>(sh_obs + 4 * k);   // wave-uniform
         const double yn[3] = {nat.v[0] - o.x, nat.v[1] - o.y, nat.v[K - 1] - o.z};
         const double d = fma(yn[2], yn[2], fma(yn[1], yn[1], yn[0] * yn[0]));
         const double cl = obs_lane ? fmax(o.w - d, 0.0) : 0.0;
         if (__builtin_amdgcn_ballot_w64(cl != 0.0) == 0ull) continue;   // nobody touches obstacle k
         double y[K];
-#pragma unroll
-        for (int q = 0; q < K; ++q) {
-          const int r = arot[q];
-          y[q] = r == 0 ? yn[0] : (r == 1 ? yn[1] : yn[2]);
-        }
+        rotate_nat(yn, y);
         const double c = -cl;
         const double a2 = (cl != 0.0) ? 2.0 * y[0] : 0.0;
 #pragma unroll

@@ -25,7 +25,25 @@ def _packaged(name):
     return rec["num_joints"], T
 
 
-def _make(n, T_zero, limits):
+def _randomize_links(T, pct):
+    """randomized_links of make_Revolute3d (roboturdf.py:236-244): the translation between
+    consecutive frames is scaled by (1 - pct) + 2 pct U, one np.random.rand() per link, entries below
+    1e-6 zeroed.  As in the reference the list is modified in place while it is read, so link idx is
+    measured from the ALREADY MODIFIED frame idx to the original frame idx + 1.  (Applied to the
+    frames re-based on p0: relative transforms do not change under the common left factor.)"""
+    T = [np.array(M, dtype=float) for M in T]
+    for idx in range(len(T) - 1):
+        D = np.linalg.inv(T[idx]) @ T[idx + 1]
+        t = D[:3, 3] * ((1 - pct) + 2 * pct * np.random.rand())
+        t[np.abs(t) < 1e-6] = 0
+        D[:3, 3] = t
+        T[idx + 1] = T[idx] @ D
+    return np.array(T)
+
+
+def _make(n, T_zero, limits, randomized_links=False, randomize_percentage=0.4):
+    if randomized_links:
+        T_zero = _randomize_links(T_zero, randomize_percentage)
     if limits is None:  # roboturdf.py:318-320
         ub = np.ones(n) * np.pi
         lb = -ub
@@ -39,21 +57,15 @@ def _make(n, T_zero, limits):
 
 
 def load_schunk_lwa4d(limits=None, randomized_links=False, randomize_percentage=0.4):
-    if randomized_links:
-        raise NotImplementedError("randomized_links is outside the hot path")
-    return _make(*_packaged("lwa4d"), limits)
+    return _make(*_packaged("lwa4d"), limits, randomized_links, randomize_percentage)
 
 
 def load_ur10(limits=None, randomized_links=False, randomize_percentage=0.4):
-    if randomized_links:
-        raise NotImplementedError("randomized_links is outside the hot path")
-    return _make(*_packaged("ur10"), limits)
+    return _make(*_packaged("ur10"), limits, randomized_links, randomize_percentage)
 
 
 def load_kuka(limits=None, randomized_links=False, randomize_percentage=0.4):
-    if randomized_links:
-        raise NotImplementedError("randomized_links is outside the hot path")
-    return _make(*_packaged("kuka"), limits)
+    return _make(*_packaged("kuka"), limits, randomized_links, randomize_percentage)
 
 
 def load_truncated_ur10(n):
@@ -152,9 +164,9 @@ class RobotURDF:
 
     def make_Revolute3d(self, ub, lb, randomized_links=False, randomize_percentage=0.4):
         """Frames labelled p0..pn and re-based on p0 (roboturdf.py:226-264)."""
-        if randomized_links:
-            raise NotImplementedError("randomized_links is outside the hot path")
         T = self.T_zero_list
+        if randomized_links:
+            T = list(_randomize_links(T, randomize_percentage))
         if len(T) != self.n_q_joints + 1:
             raise NotImplementedError("expected exactly one fixed end-effector joint after the chain")
         T0inv = np.linalg.inv(T[0])

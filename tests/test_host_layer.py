@@ -278,3 +278,19 @@ def test_tree_robot_realization_and_joint_variables():
         T_goal = {ee: robot.pose(q_goal, ee) for ee in robot.end_effectors}
         q_rec = graph.joint_variables(graph.realization(q_goal), T_goal)
         np.testing.assert_allclose([q_goal[k] for k in sorted(q_goal)], [q_rec[k] for k in sorted(q_rec)], rtol=1e-5)
+
+
+def test_randomized_links_match_reference():
+    """load_*(randomized_links=True) (roboturdf.py:236-244: one np.random.rand() per link scales
+    the translation between consecutive zero-configuration frames) against frames captured from
+    the reference's loaders with the same seed (host_kats.npz)."""
+    from graphik_amd.utils.roboturdf import load_kuka, load_schunk_lwa4d, load_ur10
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "host_kats.npz"))
+    for nm, ld in (("lwa4d", load_schunk_lwa4d), ("ur10", load_ur10), ("kuka", load_kuka)):
+        np.random.seed(5)
+        robot, graph = ld(randomized_links=True, randomize_percentage=0.3)
+        T = np.stack([robot.nodes[f"p{i}"]["T0"].as_matrix() for i in range(robot.n + 1)])
+        assert np.abs(T - d[f"{nm}_randomized_T0"]).max() < 1e-14
+        plain, _ = ld()
+        assert np.abs(T - plain.T0_array()).max() > 1e-3                 # it does change the arm
+        assert graph.number_of_nodes() == 2 * robot.n + 4

@@ -331,6 +331,10 @@ def host_kats():
         out[f"{nm}_fk_T"] = np.array(Ts)
         out[f"{nm}_realization"] = np.array(Ps)
         out[f"{nm}_jointvars"] = np.array(Qr)
+    for nm, ld in (("lwa4d", load_schunk_lwa4d), ("ur10", load_ur10), ("kuka", load_kuka)):
+        np.random.seed(5)                       # randomized_links (roboturdf.py:236-244)
+        robot, _ = ld(randomized_links=True, randomize_percentage=0.3)
+        out[f"{nm}_randomized_T0"] = np.stack([robot.nodes[f"p{i}"]["T0"].as_matrix() for i in range(robot.n + 1)])
     robot, graph = planar_chain(10)
     rng = np.random.RandomState(7)
     Q = rng.uniform(-np.pi, np.pi, size=(5, 10))

@@ -2,7 +2,7 @@
 """tools/summarize_prof.py -- turn the rocprofv3 CSVs of tools/profile.sh into the small summaries
 kept under profiles/ (run here after gpurun merged gpurun_out/prof back).
 
-    python tools/summarize_prof.py [round_tag]        # default r01
+    python tools/summarize_prof.py [tag]              # default r02 (reads gpurun_out/prof_<tag>/)
 
 Writes
     profiles/<tag>_kernel_stats.csv     per-kernel durations (copy of rocprofv3 --stats)
@@ -21,8 +21,8 @@ import sys
 from collections import defaultdict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(REPO, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+P = os.path.join(REPO, "gpurun_out", "prof_" + tag)
 out = os.path.join(REPO, "profiles")
 os.makedirs(out, exist_ok=True)
 
@@ -47,16 +47,16 @@ for k, cs in summary.items():
     cs["_dispatches"] = len(next(iter(per[k].values())))
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc_per_launch.json"), "w"), indent=1)
 
-solve = next(k for k in summary if "rtr_wave_kernel" in k)
+solve = next(k for k in summary if "rtr_wave_kernel" in k or "rtr_block_kernel" in k)
 fetch = summary[solve]["FETCH_SIZE"] * 1024 * 2
 write = summary[solve]["WRITE_SIZE"] * 1024
 json.dump({"kernel": solve, "bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch,
            "write_bytes": write,
            "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, "
-                  "tools/profile.sh), bench.py --steps 2 --warmup 1, mean over the dispatches; "
+                  "tools/profile.sh %s), bench.py --steps 2 --warmup 1, mean over the dispatches; " % tag +
                   "FETCH_SIZE (KiB) x1024 x2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM "
                   "section), WRITE_SIZE (KiB) x1024"},
-          open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
+          open(os.path.join(out, "hbm_traffic.json" if tag == "r02" else f"{tag}_hbm_traffic.json"), "w"), indent=1)
 
 for line in open(os.path.join(P, "kt_bench.json")):
     if line.startswith("{"):
