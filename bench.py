@@ -428,7 +428,7 @@ def main():
             out["roofline"]["traffic"] = tj.get("bytes_per_launch")
             out["roofline"]["traffic_source"] = ("profiles/hbm_traffic.json: rocprofv3 --pmc passes of "
                                                  "this command in a separate run (" +
-                                                 str(tj.get("source", "see profiles/README")) + "), not "
+                                                 "tools/profile.sh r02 + tools/summarize_prof.py" + "), not "
                                                  "measured by the process that printed this line")
         except Exception:
             pass
