@@ -40,6 +40,10 @@ struct PipeConst {
   int last_along_z;           // joint_variables: last link offset parallel to z (:314)
 };
 
+// A rotation is skipped when |a_pq| <= 1e-16 |A|_F, and the sweeps stop after the first one without a
+// rotation.  (Relaxing the threshold buys nothing -- measured and emulated: the Gram matrices here
+// are rank deficient and cyclic Jacobi spends ~6 sweeps in its linear phase whatever the threshold
+// between 1e-16 and 1e-12, then collapses within one sweep.)
 // round-robin (chess tournament) pairing: n_even players, round r, table m
 __device__ inline void rr_pair(int n_even, int r, int m, int &p, int &q) {
   if (m == 0) {

@@ -622,7 +622,6 @@ struct WaveCtx {
         ba[0] += c;
         G = fma(c, y[0], G);
       }
-#pragma unroll 4
       for (int k = 0; k < n_obs; ++k) {
         const double4 o = *reinterpret_cast<const double4 *>(sh_obs + 4 * k);   // wave-uniform
         const double yn[3] = {nat.v[0] - o.x, nat.v[1] - o.y, nat.v[K - 1] - o.z};
