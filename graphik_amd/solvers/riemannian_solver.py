@@ -150,10 +150,14 @@ class BatchProblem:
         self.use_limits = use_limits
         N = graph.number_of_nodes()
         n = self.robot.n
-        ee = f"p{n}"
-        # goal nodes and how their positions follow from the goal pose (_pose_goal)
+        self.end_effectors = list(self.robot.end_effectors)
+        self.multi_ee = len(self.end_effectors) > 1
+        ee = self.end_effectors[0]
+        # goal nodes and how their positions follow from the goal pose (_pose_goal); a robot with
+        # several end effectors (3-D trees) has a (p, q) pair per end effector and takes goals
+        # [B, n_ee, 4, 4] in the order of robot.end_effectors
         if self.dim == 3:
-            self.goal_nodes = [graph.index(ee), graph.index(f"q{n}")]
+            self.goal_nodes = [graph.index(c + e[1:]) for e in self.end_effectors for c in "pq"]
         else:
             self.goal_nodes = [graph.index(ee), graph.index(f"p{n - 1}")]
         self.anchor_nodes = [i for i, name in enumerate(graph.node_ids)
@@ -161,7 +165,8 @@ class BatchProblem:
         self.anchor_pos = np.array([graph.nodes[graph.node_ids[i]][POS] for i in self.anchor_nodes],
                                    dtype=float)
         # a goal instance with a dummy pose gives the complete edge pattern (omega)
-        G0 = graph.from_pose(self.robot.pose(self.robot.zero_configuration(), ee))
+        q0 = self.robot.zero_configuration()
+        G0 = graph.from_pose({e: self.robot.pose(q0, e) for e in self.end_effectors})
         self.omega = dgp.adjacency_matrix_from_graph(G0)
         self.base_D = dgp.distance_matrix_from_graph(G0)
         self.base_lower = np.where(G0.edge, G0.lower, np.nan)
@@ -179,8 +184,10 @@ class BatchProblem:
         """Hand the goal-independent pre/post-processing data to the device handle."""
         g, T = self.graph, self.template
         n = self.robot.n
-        if len(self.anchor_nodes) > 256 or self.N > 128:
-            self.device_pipeline = False   # beyond the device prepare kernels: host pre/post
+        if len(self.anchor_nodes) > 256 or self.N > 128 or self.multi_ee:
+            # beyond the device prepare / recover kernels (one end effector, N <= 128): host
+            # pre/post-processing around the device solve
+            self.device_pipeline = False
             return
         goalset = set(self.goal_nodes)
         slot = {a: s for s, a in enumerate(self.anchor_nodes)}
@@ -227,9 +234,11 @@ class BatchProblem:
         T = np.asarray(T_goals, dtype=float)
         d = self.dim
         if d == 3:
-            p = T[:, :3, 3]
-            q = p + T[:, :3, 2] * self.graph.axis_length
-            return np.stack((p, q), axis=1)
+            if T.ndim == 3:
+                T = T[:, None]                           # one end effector
+            p = T[:, :, :3, 3]
+            q = p + T[:, :, :3, 2] * self.graph.axis_length
+            return np.stack((p, q), axis=2).reshape(T.shape[0], -1, 3)   # p_e, q_e per end effector
         ee, pred = self.goal_nodes
         dist = self.graph.dist[pred, ee]
         p = T[:, :2, 2]
@@ -248,6 +257,13 @@ class BatchProblem:
                 D[:, a, g] = D[:, g, a] = dist[:, ai] ** 2
                 lo[:, a, g] = lo[:, g, a] = dist[:, ai]
                 up[:, a, g] = up[:, g, a] = dist[:, ai]
+            for hi in range(gi + 1, len(self.goal_nodes)):   # goal nodes of DIFFERENT end effectors
+                h = self.goal_nodes[hi]
+                if self.omega[g, h] != 0 and np.isnan(self.graph.dist[g, h]):
+                    dd = np.linalg.norm(gp[:, gi] - gp[:, hi], axis=-1)
+                    D[:, g, h] = D[:, h, g] = dd ** 2
+                    lo[:, g, h] = lo[:, h, g] = dd
+                    up[:, g, h] = up[:, h, g] = dd
         return D, lo, up
 
     def prepare(self, T_goals, chunk=None, workers=None):
@@ -279,15 +295,24 @@ class BatchProblem:
         from ..graphs.graph_revolute import joint_variables_revolute_batch
         from ..graphs.graph_planar import joint_variables_planar_batch
         if self.dim == 3:
-            return joint_variables_revolute_batch(self.graph, Y, np.asarray(T_goals, dtype=float))
+            T = np.asarray(T_goals, dtype=float)
+            if T.ndim == 4:
+                T = {e: T[:, i] for i, e in enumerate(self.end_effectors)}
+            return joint_variables_revolute_batch(self.graph, Y, T)
         return joint_variables_planar_batch(self.graph, Y)
 
     def pose_errors(self, q, T_goals):
         """EE position / rotation error of FK(q) against the goals (the metric of
         experiments/simple_ik_examples/test_chain_2d_new.py:62-66)."""
         T_goals = np.asarray(T_goals, dtype=float)
-        T_sol = self.robot.fk_batch(q)
-        d = self.dim
+        if T_goals.ndim == 4:        # several end effectors: the worst of them
+            errs = [BatchProblem._pose_err(self.robot.fk_batch(q, int(e[1:])), T_goals[:, i], self.dim)
+                    for i, e in enumerate(self.end_effectors)]
+            return np.max([e[0] for e in errs], axis=0), np.max([e[1] for e in errs], axis=0)
+        return BatchProblem._pose_err(self.robot.fk_batch(q), T_goals, self.dim)
+
+    @staticmethod
+    def _pose_err(T_sol, T_goals, d):
         pos = np.linalg.norm(T_goals[:, :d, d] - T_sol[:, :d, d], axis=1)
         Rrel = T_goals[:, :d, :d] @ np.swapaxes(T_sol[:, :d, :d], 1, 2)
         if d == 3:
@@ -468,7 +493,10 @@ def solve_batch(graph, T_goals, use_limits=True, params=None, device=None, Y_ini
 def solve_with_riemannian(graph, T_goal, use_jit=True, jit=None):
     """riemannian_solver.py:220-234 on the GPU engine (B = 1).  `jit=` is accepted as an alias of
     `use_jit=` because the reference's README spells it that way (README.md:45)."""
-    T = as_matrix(T_goal)[None]
+    if isinstance(T_goal, dict):     # several end effectors: {end effector: pose}
+        T = np.stack([as_matrix(T_goal[e]) for e in graph.robot.end_effectors])[None]
+    else:
+        T = as_matrix(T_goal)[None]
     q, Y, info = solve_batch(graph, T)
     q_sol = graph.robot.array_to_q(q[0])
     broken = graph.check_distance_limits(graph.realization(q_sol), tol=1e-6)

@@ -1141,3 +1141,34 @@ def test_anchored_pipeline(torch_cuda):
     g = ap.base.graph
     assert np.abs(Y[:, g.index("p0")]).max() == 0.0
     assert np.abs(Y[:, g.index(f"p{robot.n}")] - Tg[:, :3, 3]).max() < 1e-15
+
+
+def test_tree_robot_solve_batch(torch_cuda):
+    """solve_batch / solve_with_riemannian for a robot with two end effectors (goals [B, n_ee, 4, 4]
+    in the order of robot.end_effectors, or a dict for the single call): host pre/post-processing
+    around the device solve.  The assembled distance matrices and bounds equal the captured
+    reference's; random goals are reached by BOTH end effectors."""
+    from test_host_layer import tree_robot
+    from graphik_amd.solvers.riemannian_solver import BatchProblem, solve_batch, solve_with_riemannian
+    from graphik_amd.utils import dgp
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree5.npz"))
+    robot, graph = tree_robot()
+    prob = BatchProblem(graph, use_limits=True)
+    assert prob.multi_ee and not prob.device_pipeline
+    G = len(d["sol_f"])
+    D, lo, up = prob.assemble(d["T_goal"][:G])
+    assert np.abs(D - d["sol_D_goal"]).max() < 1e-13
+    lb, ub = dgp.floyd_warshall_bounds(lo, up)
+    assert np.abs(lb - d["sol_lb"]).max() < 1e-12 and np.abs(ub - d["sol_ub"]).max() < 1e-12
+    rng = np.random.RandomState(6)
+    B = 64
+    lbq, ubq = robot.limits_arrays()
+    Q = lbq + (ubq - lbq) * rng.rand(B, robot.n)
+    Tg = np.stack([robot.fk_batch(Q, int(e[1:])) for e in robot.end_effectors], axis=1)      # [B, 2, 4, 4]
+    q, Y, info = solve_batch(graph, Tg)
+    assert Y.shape == (B, graph.number_of_nodes(), 3) and q.shape == (B, robot.n)
+    assert np.mean(info["pos_err"] < 1e-6) > 0.9 and np.all(info["stop"] != 2)
+    q1, Y1 = solve_with_riemannian(graph, {e: Tg[0, i] for i, e in enumerate(robot.end_effectors)})
+    assert set(q1) == {f"p{i}" for i in range(1, 6)}
+    for i, e in enumerate(robot.end_effectors):
+        assert np.linalg.norm(robot.pose(q1, e).trans - Tg[0, i][:3, 3]) < 1e-6
