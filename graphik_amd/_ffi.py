@@ -67,7 +67,10 @@ class PipelineDesc(C.Structure):
         ("n_pairs", C.c_int32), ("pair_i", C.POINTER(C.c_int32)), ("pair_j", C.POINTER(C.c_int32)),
         ("term_src", C.POINTER(C.c_int32)), ("term_static", C.POINTER(C.c_double)),
         ("last_link_along_z", C.c_int32), ("jacobi_sweeps", C.c_int32),
-        ("force_block_prepare", C.c_int32), ("reserved0", C.c_int32),
+        ("force_block_prepare", C.c_int32), ("n_ee", C.c_int32),
+        ("ee_goal_nodes", C.POINTER(C.c_int32)), ("ee_path", C.POINTER(C.c_int32)),
+        ("n_goal_pairs", C.c_int32), ("reserved1", C.c_int32),
+        ("goal_pair_a", C.POINTER(C.c_int32)), ("goal_pair_b", C.POINTER(C.c_int32)),
     ]
 
 

@@ -33,12 +33,57 @@ struct PipeConst {
   const double *T0;           // [n+1][(K+1)^2] frames at zero configuration (row-major)
   const int *p_idx, *q_idx;   // [n+1] node index of p_i / q_i
   int N, K, T, n_anchor, n_pairs, n_joints;
-  int goal0, goal1;           // ee node, and q_n (k=3) or p_{n-1} (k=2)
+  int goal0, goal1;           // ee node, and q_n (k=3) or p_{n-1} (k=2)   (first end effector)
   int x_idx, y_idx;
   double goal_len;            // axis_length (k=3) / |p_{n-1} p_n| (k=2)
   double axis_length;
-  int last_along_z;           // joint_variables: last link offset parallel to z (:314)
+  int last_along_z;           // joint_variables: last link offset parallel to z (:314), bit e = end effector e
+  // several end effectors (k = 3 trees): goal poses are [B][n_ee][16]; goal node 2e / 2e+1 is
+  // (p, q) of end effector e.  Distances: gd[ai * 2 n_ee + g] anchor ai <-> goal node g, then the
+  // n_gg goal-node pairs of DIFFERENT end effectors.  A chain has n_ee = 1, n_gg = 0 (the layout
+  // and arithmetic of the single-end-effector kernels, bit for bit).
+  int n_ee, n_gg;
+  int goal_node[2 * 4];       // graph node of goal node g
+  const int *gg_a, *gg_b;     // [n_gg] goal-node slots of each pair
+  const int *ee_path;         // [n_ee][n+1] joints from the root to end effector e, -1 padded
 };
+constexpr int PREP_MAX_EE = 4;
+
+// position of goal node g = 2 e + s of problem `Tg` ([n_ee][(K+1)^2]): p_e, or q_e = p_e + len z_e
+// (graph_revolute.py:243-249); k = 2: p_n, p_{n-1} = p_n - len x_n (graph_planar.py:136-145)
+__device__ inline void goal_node_pos(const PipeConst &pc, const double *Tg, int g, double (&w)[3]) {
+  const int K = pc.K, D = K + 1;
+  const double *T = Tg + (size_t)(g >> 1) * D * D;
+  for (int c = 0; c < K; ++c) {
+    const double p = T[c * D + K];
+    w[c] = !(g & 1) ? p : ((K == 3) ? p + T[c * D + 2] * pc.goal_len : p - T[c * D + 0] * pc.goal_len);
+  }
+}
+
+// anchor <-> goal and goal <-> goal distances of one problem: entry idx of gd (see PipeConst)
+__device__ inline double goal_distance(const PipeConst &pc, const double *Tg, int idx, int &na, int &nb) {
+  const int K = pc.K, G = 2 * pc.n_ee;
+  double a[3], b[3];
+  if (idx < G * pc.n_anchor) {
+    const int ai = idx / G, g = idx - ai * G;
+    for (int c = 0; c < K; ++c) a[c] = pc.anchor_pos[ai * K + c];
+    goal_node_pos(pc, Tg, g, b);
+    na = pc.anchor_idx[ai];
+    nb = pc.goal_node[g];
+  } else {
+    const int q = idx - G * pc.n_anchor;
+    goal_node_pos(pc, Tg, pc.gg_a[q], a);
+    goal_node_pos(pc, Tg, pc.gg_b[q], b);
+    na = pc.goal_node[pc.gg_a[q]];
+    nb = pc.goal_node[pc.gg_b[q]];
+  }
+  double d2 = 0.0;
+  for (int c = 0; c < K; ++c) {
+    const double df = a[c] - b[c];
+    d2 += df * df;
+  }
+  return sqrt(d2);   // np.linalg.norm
+}
 
 // A rotation is skipped when |a_pq| <= 1e-16 |A|_F, and the sweeps stop after the first one without a
 // rotation.  (Relaxing the threshold buys nothing -- measured and emulated: the Gram matrices here
@@ -180,8 +225,8 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
   double *A = L + NN;          // work matrix
   double *V = A + NN;          // eigenvectors / temp
   double *X = V + NN;          // MDS factor
-  double *gd = X + NN;         // [2*n_anchor] anchor<->goal distances
-  double *cs = gd + 2 * pc.n_anchor + (pc.n_anchor & 1) * 0;
+  double *gd = X + NN;         // [2 n_ee n_anchor + n_gg] anchor<->goal and goal<->goal distances
+  double *cs = gd + 2 * pc.n_ee * pc.n_anchor + pc.n_gg;
   double *ev = cs + 32;        // [32] eigenvalues / row means
   double *sg = ev + 32;        // [32] signs*scale
   int *pq = reinterpret_cast<int *>(sg + 32);  // [16]
@@ -189,13 +234,8 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
   const int D = K + 1;
 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    const double *Tg = a.T_goal + (size_t)b * D * D;
-    // goal node positions (_pose_goal, graph_revolute.py:243-249 / graph_planar.py:136-145)
-    double g0[3], g1[3];
-    for (int c = 0; c < K; ++c) {
-      g0[c] = Tg[c * D + K];
-      g1[c] = (K == 3) ? g0[c] + Tg[c * D + 2] * pc.goal_len : g0[c] - Tg[c * D + 0] * pc.goal_len;
-    }
+    const double *Tg = a.T_goal + (size_t)b * D * D * pc.n_ee;
+    const int n_gd = 2 * pc.n_ee * pc.n_anchor + pc.n_gg;
     for (int e = lane; e < NN; e += WAVE) {
       const double lo = pc.base_lower[e], up = pc.base_upper[e];
       const bool diag = (e / N) == (e % N);
@@ -203,16 +243,11 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
       L[e] = diag ? 0.0 : (lo == lo ? lo : -INFINITY);
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane < 2 * pc.n_anchor) {
-      const int ai = lane >> 1, gs = lane & 1;
-      double d2 = 0.0;
-      for (int c = 0; c < K; ++c) {
-        const double df = pc.anchor_pos[ai * K + c] - (gs ? g1[c] : g0[c]);
-        d2 += df * df;
-      }
-      const double d = sqrt(d2);   // np.linalg.norm
-      gd[lane] = d;
-      const int an = pc.anchor_idx[ai], gn = gs ? pc.goal1 : pc.goal0;
+    // goal nodes (_pose_goal) and the distances graph_complete_edges gives them (dgp.py:124-147)
+    for (int idx = lane; idx < n_gd; idx += WAVE) {
+      int an, gn;
+      const double d = goal_distance(pc, Tg, idx, an, gn);
+      gd[idx] = d;
       U[an * N + gn] = U[gn * N + an] = d;
       L[an * N + gn] = L[gn * N + an] = d;
     }
@@ -460,7 +495,7 @@ __device__ inline void jacobi_blk(double *A, double *V, int N, int sweeps, doubl
 }
 
 __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double *ws) {
-  __shared__ double gd[2 * PREP_MAXA];
+  __shared__ double gd[2 * PREP_MAXA + 16];     // (several end effectors: checked at attach)
   __shared__ double cs[2 * (PREP_MAXN / 2)];
   __shared__ double ev[PREP_MAXN], sg[PREP_MAXN], red[PREP_NT / 64];
   __shared__ int pq[PREP_MAXN / 2], rk[PREP_MAXN];
@@ -475,12 +510,8 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
   const int D = K + 1;
 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    const double *Tg = a.T_goal + (size_t)b * D * D;
-    double g0[3], g1[3];
-    for (int c = 0; c < K; ++c) {
-      g0[c] = Tg[c * D + K];
-      g1[c] = (K == 3) ? g0[c] + Tg[c * D + 2] * pc.goal_len : g0[c] - Tg[c * D + 0] * pc.goal_len;
-    }
+    const double *Tg = a.T_goal + (size_t)b * D * D * pc.n_ee;
+    const int n_gd = 2 * pc.n_ee * pc.n_anchor + pc.n_gg;
     for (int e = tid; e < NN; e += PREP_NT) {
       const double lo = pc.base_lower[e], up = pc.base_upper[e];
       const bool diag = (e / N) == (e % N);
@@ -488,16 +519,10 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       L[e] = diag ? 0.0 : (lo == lo ? lo : -INFINITY);
     }
     __syncthreads();
-    if (tid < 2 * pc.n_anchor) {
-      const int ai = tid >> 1, gs = tid & 1;
-      double d2 = 0.0;
-      for (int c = 0; c < K; ++c) {
-        const double df = pc.anchor_pos[ai * K + c] - (gs ? g1[c] : g0[c]);
-        d2 += df * df;
-      }
-      const double d = sqrt(d2);   // np.linalg.norm
-      gd[tid] = d;
-      const int an = pc.anchor_idx[ai], gn = gs ? pc.goal1 : pc.goal0;
+    for (int idx = tid; idx < n_gd; idx += PREP_NT) {
+      int an, gn;
+      const double d = goal_distance(pc, Tg, idx, an, gn);
+      gd[idx] = d;
       U[an * N + gn] = U[gn * N + an] = d;
       L[an * N + gn] = L[gn * N + an] = d;
     }
@@ -711,7 +736,6 @@ __global__ void recover_kernel(RecoverArgs a) {
   const double *P = a.Y + (size_t)b * N * K;
   double *q = a.q + (size_t)b * n;
   if (K == 3) {
-    const double *Tg = a.T_goal + (size_t)b * 16;
     const double *p0 = P + pc.p_idx[0] * 3;
     // base frame from the recovered anchors: R = [x^, -y^, z^]  (graph_revolute.py:263-279)
     double R[9];
@@ -726,66 +750,79 @@ __global__ void recover_kernel(RecoverArgs a) {
       const double sc = (nr == 0.0 ? 1.0 : 1.0 / nr) * (c == 1 ? -1.0 : 1.0);
       for (int t = 0; t < 3; ++t) R[t * 3 + c] = v[t] * sc;
     }
-    double Tp[16], Trel[16], tmp[16], inv[16];
-    for (int t = 0; t < 16; ++t) Tp[t] = pc.T0[t];  // T[ROOT] = robot.T_base
-    double th = 0.0;
-    for (int idx = 1; idx <= n; ++idx) {
-      mat4_inv_rigid(pc.T0 + (idx - 1) * 16, inv);
-      mat4_mul(inv, pc.T0 + idx * 16, Trel);  // T_rel = T_prev_0^-1 T_0
-      // qs_0 = (T_prev_0^-1 T_0 trans_z(a)).trans
-      double qs0[2];
-      for (int t = 0; t < 2; ++t) qs0[t] = Trel[t * 4 + 3] + Trel[t * 4 + 2] * pc.axis_length;
-      const double *pc_ = P + pc.p_idx[idx] * 3, *qc = P + pc.q_idx[idx] * 3;
-      double dq[3], nr = 0.0;
-      for (int t = 0; t < 3; ++t) {
-        dq[t] = qc[t] - pc_[t];
-        nr += dq[t] * dq[t];
+    double worst_p = 0.0, worst_r = 0.0;
+    // one walk from the root per end effector (graph_revolute.py:285-316; joints shared by several
+    // paths get the same angle from each)
+    for (int e = 0; e < pc.n_ee; ++e) {
+      const double *Tg = a.T_goal + ((size_t)b * pc.n_ee + e) * 16;
+      const int *path = pc.ee_path + e * (n + 1);
+      double Tp[16], Trel[16], tmp[16], inv[16];
+      for (int t = 0; t < 16; ++t) Tp[t] = pc.T0[t];  // T[ROOT] = robot.T_base
+      double th = 0.0;
+      int cur = 0, last = 0;
+      for (int k = 1; k <= n && path[k] >= 0; ++k) last = k;
+      for (int k = 1; k <= last; ++k) {
+        const int pred = path[k - 1];
+        cur = path[k];
+        mat4_inv_rigid(pc.T0 + pred * 16, inv);
+        mat4_mul(inv, pc.T0 + cur * 16, Trel);  // T_rel = T_prev_0^-1 T_0
+        // qs_0 = (T_prev_0^-1 T_0 trans_z(a)).trans
+        double qs0[2];
+        for (int t = 0; t < 2; ++t) qs0[t] = Trel[t * 4 + 3] + Trel[t * 4 + 2] * pc.axis_length;
+        const double *pc_ = P + pc.p_idx[cur] * 3, *qc = P + pc.q_idx[cur] * 3;
+        double dq[3], nr = 0.0;
+        for (int t = 0; t < 3; ++t) {
+          dq[t] = qc[t] - pc_[t];
+          nr += dq[t] * dq[t];
+        }
+        nr = sqrt(nr);
+        double qn[3], qb[3];
+        for (int t = 0; t < 3; ++t) qn[t] = pc_[t] + dq[t] / nr - p0[t];
+        for (int t = 0; t < 3; ++t) qb[t] = R[0 * 3 + t] * qn[0] + R[1 * 3 + t] * qn[1] + R[2 * 3 + t] * qn[2];
+        double qs[2];
+        for (int t = 0; t < 2; ++t)
+          qs[t] = Tp[0 * 4 + t] * (qb[0] - Tp[3]) + Tp[1 * 4 + t] * (qb[1] - Tp[7]) +
+                  Tp[2 * 4 + t] * (qb[2] - Tp[11]);
+        th = atan2(qs0[0] * qs[1] - qs0[1] * qs[0], qs0[0] * qs[0] + qs0[1] * qs[1]);  // :308
+        q[cur - 1] = th;
+        if (k == last) break;  // keep T_prev of the last joint for the T_final correction
+        const double c = cos(th), s = sin(th);
+        double Rz[16] = {c, -s, 0, 0, s, c, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        mat4_mul(Tp, Rz, tmp);
+        mat4_mul(tmp, Trel, Tp);  // :310
       }
-      nr = sqrt(nr);
-      double qn[3], qb[3];
-      for (int t = 0; t < 3; ++t) qn[t] = pc_[t] + dq[t] / nr - p0[t];
-      for (int t = 0; t < 3; ++t) qb[t] = R[0 * 3 + t] * qn[0] + R[1 * 3 + t] * qn[1] + R[2 * 3 + t] * qn[2];
-      double qs[2];
-      for (int t = 0; t < 2; ++t)
-        qs[t] = Tp[0 * 4 + t] * (qb[0] - Tp[3]) + Tp[1 * 4 + t] * (qb[1] - Tp[7]) +
-                Tp[2 * 4 + t] * (qb[2] - Tp[11]);
-      th = atan2(qs0[0] * qs[1] - qs0[1] * qs[0], qs0[0] * qs[0] + qs0[1] * qs[1]);  // :308
-      q[idx - 1] = th;
-      if (idx == n) break;  // keep T_prev of the last joint for the T_final correction
-      const double c = cos(th), s = sin(th);
-      double Rz[16] = {c, -s, 0, 0, s, c, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-      mat4_mul(Tp, Rz, tmp);
-      mat4_mul(tmp, Trel, Tp);  // :310
+      // T[ee] with the uncorrected last angle
+      double Tee[16];
+      {
+        const double c = cos(th), s = sin(th);
+        double Rz[16] = {c, -s, 0, 0, s, c, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        mat4_mul(Tp, Rz, tmp);
+        mat4_mul(tmp, Trel, Tee);
+      }
+      if ((pc.last_along_z >> e) & 1) {  // :314-316
+        // T_final expressed in the recovered base frame is the goal itself (T_base = identity
+        // re-basing happened at load time); T_th = T[ee]^-1 T_final
+        mat4_inv_rigid(Tee, inv);
+        mat4_mul(inv, Tg, tmp);
+        th = wrap_pi(th + atan2(tmp[4], tmp[0]));
+        q[cur - 1] = th;
+        const double c = cos(th), s = sin(th);
+        double Rz[16] = {c, -s, 0, 0, s, c, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        mat4_mul(Tp, Rz, tmp);
+        mat4_mul(tmp, Trel, Tee);
+      }
+      // pose error of FK(q) = T[ee] against the goal
+      double dp = 0.0, tr = 0.0;
+      for (int t = 0; t < 3; ++t) {
+        const double df = Tg[t * 4 + 3] - Tee[t * 4 + 3];
+        dp += df * df;
+        for (int u = 0; u < 3; ++u) tr += Tg[t * 4 + u] * Tee[t * 4 + u];  // trace(Rg Rs^T)
+      }
+      worst_p = fmax(worst_p, sqrt(dp));
+      worst_r = fmax(worst_r, acos(fmin(1.0, fmax(-1.0, 0.5 * tr - 0.5))));
     }
-    // T[ee] with the uncorrected last angle
-    double Tee[16];
-    {
-      const double c = cos(th), s = sin(th);
-      double Rz[16] = {c, -s, 0, 0, s, c, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-      mat4_mul(Tp, Rz, tmp);
-      mat4_mul(tmp, Trel, Tee);
-    }
-    if (pc.last_along_z) {  // :314-316
-      // T_final expressed in the recovered base frame is the goal itself (T_base = identity
-      // re-basing happened at load time); T_th = T[ee]^-1 T_final
-      mat4_inv_rigid(Tee, inv);
-      mat4_mul(inv, Tg, tmp);
-      th = wrap_pi(th + atan2(tmp[4], tmp[0]));
-      q[n - 1] = th;
-      const double c = cos(th), s = sin(th);
-      double Rz[16] = {c, -s, 0, 0, s, c, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-      mat4_mul(Tp, Rz, tmp);
-      mat4_mul(tmp, Trel, Tee);
-    }
-    // pose error of FK(q) = T[ee] against the goal
-    double dp = 0.0, tr = 0.0;
-    for (int t = 0; t < 3; ++t) {
-      const double df = Tg[t * 4 + 3] - Tee[t * 4 + 3];
-      dp += df * df;
-      for (int u = 0; u < 3; ++u) tr += Tg[t * 4 + u] * Tee[t * 4 + u];  // trace(Rg Rs^T)
-    }
-    a.pos_err[b] = sqrt(dp);
-    a.rot_err[b] = acos(fmin(1.0, fmax(-1.0, 0.5 * tr - 0.5)));
+    a.pos_err[b] = worst_p;     // (several end effectors: the worst of them)
+    a.rot_err[b] = worst_r;
   } else {
     const double *Tg = a.T_goal + (size_t)b * 9;
     // best_fit_transform of (p0, x, y) onto ((0,0), (-1,0), (0,1)) without reflection handling

@@ -1113,6 +1113,33 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   pc.n_joints = n;
   pc.goal0 = d->goal_node0;
   pc.goal1 = d->goal_node1;
+  // end effectors: a chain is one path 0..n with goal nodes (goal_node0, goal_node1)
+  const int n_ee = d->n_ee > 1 ? d->n_ee : 1;
+  if (n_ee > PREP_MAX_EE) return fail("at most 4 end effectors");
+  if (n_ee > 1 && (K != 3 || !d->ee_goal_nodes || !d->ee_path || d->n_goal_pairs < 0 ||
+                   (d->n_goal_pairs > 0 && (!d->goal_pair_a || !d->goal_pair_b))))
+    return fail("several end effectors: k = 3 and ee_goal_nodes / ee_path / goal pairs required");
+  pc.n_ee = n_ee;
+  pc.n_gg = n_ee > 1 ? d->n_goal_pairs : 0;
+  std::vector<int> path((size_t)n_ee * (n + 1), -1);
+  if (n_ee > 1) {
+    for (int g = 0; g < 2 * n_ee; ++g) pc.goal_node[g] = d->ee_goal_nodes[g];
+    for (size_t t = 0; t < path.size(); ++t) path[t] = d->ee_path[t];
+    for (int e = 0; e < n_ee; ++e)
+      for (int k = 0; k <= n; ++k) {
+        const int j = path[(size_t)e * (n + 1) + k];
+        if (j < -1 || j > n || (k == 0 && j != 0)) return fail("bad ee_path");
+      }
+  } else {
+    pc.goal_node[0] = d->goal_node0;
+    pc.goal_node[1] = d->goal_node1;
+    for (int k = 0; k <= n; ++k) path[k] = k;
+  }
+  pc.ee_path = upload(t, path.data(), path.size(), ok);
+  pc.gg_a = pc.n_gg ? upload(t, d->goal_pair_a, pc.n_gg, ok) : nullptr;
+  pc.gg_b = pc.n_gg ? upload(t, d->goal_pair_b, pc.n_gg, ok) : nullptr;
+  if (2 * n_ee * d->n_anchor + pc.n_gg > 2 * PREP_MAXA + 16) return fail("too many anchor-goal pairs");
+  if (!ok) return fail("device upload failed");
   pc.x_idx = d->x_index;
   pc.y_idx = d->y_index;
   pc.goal_len = d->goal_len;
@@ -1120,7 +1147,7 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   pc.last_along_z = d->last_link_along_z;
   t->pc = pc;
   t->sweeps = d->jacobi_sweeps > 0 ? d->jacobi_sweeps : 10;
-  t->prep_smem = sizeof(double) * ((size_t)5 * N * N + 2 * d->n_anchor + 96) + sizeof(int) * 48;
+  t->prep_smem = sizeof(double) * ((size_t)5 * N * N + 2 * n_ee * d->n_anchor + pc.n_gg + 96) + sizeof(int) * 48;
   // graphs beyond one wavefront's LDS: workgroup-per-goal kernel with its matrices in a global slab
   t->prep_block = N > 32 || d->n_anchor > 32 || d->force_block_prepare != 0 ||
                   getenv("GIK_PREP_FORCE_BLOCK") != nullptr;

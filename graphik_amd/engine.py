@@ -248,7 +248,8 @@ class Template:
     def attach_pipeline(self, *, T0, p_index, q_index, x_index, y_index, axis_length, goal_nodes,
                         goal_len, base_lower, base_upper, anchor_index, anchor_pos, pair_i, pair_j,
                         term_src, term_static, last_link_along_z, jacobi_sweeps=0,
-                        force_block_prepare=False):
+                        force_block_prepare=False, ee_goal_nodes=None, ee_path=None,
+                        goal_pair_a=(), goal_pair_b=()):
         """Give the handle what it needs to run from_pose + bound_smoothing +
         generate_initialization and joint_variables on the device (gik_pipeline_attach)."""
         keep = {}
@@ -278,9 +279,18 @@ class Template:
         d.pair_j = arr("pj", pair_j, np.int32)
         d.term_src = arr("ts", term_src, np.int32)
         d.term_static = arr("tv", term_static, np.float64)
-        d.last_link_along_z = int(bool(last_link_along_z))
+        d.last_link_along_z = int(last_link_along_z)       # one bit per end effector
         d.jacobi_sweeps = int(jacobi_sweeps)
         d.force_block_prepare = int(bool(force_block_prepare))
+        self.n_ee = 1
+        if ee_goal_nodes is not None and len(ee_goal_nodes) > 2:     # several end effectors
+            self.n_ee = len(ee_goal_nodes) // 2
+            d.n_ee = self.n_ee
+            d.ee_goal_nodes = arr("eg", ee_goal_nodes, np.int32)
+            d.ee_path = arr("ep", ee_path, np.int32)
+            d.n_goal_pairs = len(goal_pair_a)
+            d.goal_pair_a = arr("ga", goal_pair_a, np.int32)
+            d.goal_pair_b = arr("gb", goal_pair_b, np.int32)
         with torch.cuda.device(self.device):
             _ffi.check(self.lib.gik_pipeline_attach(self._h, C.byref(d)))
         self.n_joints = int(d.n_joints)
@@ -289,7 +299,9 @@ class Template:
     def _poses(self, T_goal):
         T = _dev(T_goal, self.device)
         B = T.shape[0]
-        return T.reshape(B, (self.k + 1) ** 2).contiguous(), B
+        T = T.reshape(B, -1).contiguous()         # [B][n_ee][(k+1)^2]
+        assert T.shape[1] == getattr(self, "n_ee", 1) * (self.k + 1) ** 2, T.shape
+        return T, B
 
     def prepare(self, T_goal, return_K=False):
         """goal poses [B,k+1,k+1] -> (targets [B,T], Y_init [B,N,k]) on the device."""

@@ -184,13 +184,19 @@ class BatchProblem:
         """Hand the goal-independent pre/post-processing data to the device handle."""
         g, T = self.graph, self.template
         n = self.robot.n
-        if len(self.anchor_nodes) > 256 or self.N > 128 or self.multi_ee:
-            # beyond the device prepare / recover kernels (one end effector, N <= 128): host
+        if len(self.anchor_nodes) > 256 or self.N > 128 or len(self.end_effectors) > 4:
+            # beyond the device prepare / recover kernels (N <= 128, <= 4 end effectors): host
             # pre/post-processing around the device solve
             self.device_pipeline = False
             return
         goalset = set(self.goal_nodes)
         slot = {a: s for s, a in enumerate(self.anchor_nodes)}
+        G = len(self.goal_nodes)                     # 2 per end effector
+        # goal nodes of different end effectors that the goal graph ties by an equality edge
+        pairs = [(a, b) for a in range(G) for b in range(a + 1, G)
+                 if self.omega[self.goal_nodes[a], self.goal_nodes[b]] != 0 and
+                 np.isnan(g.dist[self.goal_nodes[a], self.goal_nodes[b]])]
+        pair_slot = {(self.goal_nodes[a], self.goal_nodes[b]): q for q, (a, b) in enumerate(pairs)}
         term_src = np.full(T.T, -1, dtype=np.int32)
         for t in range(T.T):
             i, j = int(T.term_i[t]), int(T.term_j[t])
@@ -198,7 +204,9 @@ class BatchProblem:
                 continue
             for a, gnode in ((i, j), (j, i)):
                 if gnode in goalset and a in slot:
-                    term_src[t] = slot[a] * 2 + self.goal_nodes.index(gnode)
+                    term_src[t] = slot[a] * G + self.goal_nodes.index(gnode)
+            if (i, j) in pair_slot or (j, i) in pair_slot:
+                term_src[t] = G * len(self.anchor_nodes) + pair_slot.get((i, j), pair_slot.get((j, i)))
         static = np.where(np.isnan(T.targets_static), self.base_D[T.term_i, T.term_j],
                           T.targets_static)
         lower = self.base_lower.copy()
@@ -207,18 +215,28 @@ class BatchProblem:
             for gnode in self.goal_nodes:
                 lower[a, gnode] = lower[gnode, a] = np.nan
                 upper[a, gnode] = upper[gnode, a] = np.nan
+        for a, b in pairs:
+            ga, gb = self.goal_nodes[a], self.goal_nodes[b]
+            lower[ga, gb] = lower[gb, ga] = upper[ga, gb] = upper[gb, ga] = np.nan
         I, J = np.nonzero(np.triu(self.omega))
         T0 = self.robot.T0_array()
+        ee_path = None
         if self.dim == 3:
             p_idx = [g.index(f"p{i}") for i in range(n + 1)]
             q_idx = [g.index(f"q{i}") for i in range(n + 1)]
-            rel_last = np.linalg.inv(T0[n - 1]) @ T0[n]
-            along_z = np.linalg.norm(np.cross(rel_last[:3, 3], [0, 0, 1])) < 1e-10
+            along_z = 0                                   # one bit per end effector (:314)
+            ee_path = np.full((len(self.end_effectors), n + 1), -1, dtype=np.int32)
+            for e, ee in enumerate(self.end_effectors):
+                path = [int(name[1:]) for name in self.robot.kinematic_map["p0"][ee]]
+                ee_path[e, :len(path)] = path
+                rel_last = np.linalg.inv(T0[path[-2]]) @ T0[path[-1]]
+                if np.linalg.norm(np.cross(rel_last[:3, 3], [0, 0, 1])) < 1e-10:
+                    along_z |= 1 << e
             goal_len = g.axis_length
         else:
             p_idx = [g.index(f"p{i}") for i in range(n + 1)]
             q_idx = None
-            along_z = False
+            along_z = 0
             goal_len = g.dist[self.goal_nodes[1], self.goal_nodes[0]]
         T.attach_pipeline(T0=T0, p_index=p_idx, q_index=q_idx, x_index=g.index("x"),
                           y_index=g.index("y"), axis_length=g.axis_length,
@@ -226,7 +244,9 @@ class BatchProblem:
                           base_upper=upper, anchor_index=self.anchor_nodes,
                           anchor_pos=self.anchor_pos, pair_i=I, pair_j=J, term_src=term_src,
                           term_static=static, last_link_along_z=along_z,
-                          force_block_prepare=self.force_block_prepare)
+                          force_block_prepare=self.force_block_prepare,
+                          ee_goal_nodes=self.goal_nodes if self.multi_ee else None, ee_path=ee_path,
+                          goal_pair_a=[a for a, _ in pairs], goal_pair_b=[b for _, b in pairs])
         self.device_pipeline = True
 
     def goal_positions(self, T_goals):

@@ -1145,8 +1145,9 @@ def test_anchored_pipeline(torch_cuda):
 
 def test_tree_robot_solve_batch(torch_cuda):
     """solve_batch / solve_with_riemannian for a robot with two end effectors (goals [B, n_ee, 4, 4]
-    in the order of robot.end_effectors, or a dict for the single call): host pre/post-processing
-    around the device solve.  The assembled distance matrices and bounds equal the captured
+    in the order of robot.end_effectors, or a dict for the single call): the whole device pipeline
+    (prepare with goal nodes of both end effectors and the edges between them, solve, recover by
+    one walk per end effector).  Assembled matrices, bounds and recovered angles equal the captured
     reference's; random goals are reached by BOTH end effectors."""
     from test_host_layer import tree_robot
     from graphik_amd.solvers.riemannian_solver import BatchProblem, solve_batch, solve_with_riemannian
@@ -1154,8 +1155,18 @@ def test_tree_robot_solve_batch(torch_cuda):
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree5.npz"))
     robot, graph = tree_robot()
     prob = BatchProblem(graph, use_limits=True)
-    assert prob.multi_ee and not prob.device_pipeline
+    assert prob.multi_ee and prob.device_pipeline        # prepare / recover kernels take several end effectors
     G = len(d["sol_f"])
+    # device goal assembly + bound smoothing against the captured reference (one hop)
+    dbg = prob.template.prepare_debug(d["T_goal"][:G])
+    assert np.abs(dbg["lb"].cpu().numpy() - d["sol_lb"]).max() < 1e-12
+    assert np.abs(dbg["ub"].cpu().numpy() - d["sol_ub"]).max() < 1e-12
+    tg_ref = prob.template.targets_from_D(d["sol_D_goal"])
+    assert np.abs(dbg["targets"].cpu().numpy() - tg_ref).max() < 1e-13
+    # device joint recovery of the captured solutions against the captured angles
+    q_d, pe, re = prob.template.recover(d["sol_Y_sol"], d["T_goal"][:G])
+    dq = np.abs(np.mod(q_d.cpu().numpy() - d["sol_q_sol"] + np.pi, 2 * np.pi) - np.pi)
+    assert dq.max() < 1e-9 and pe.max().item() < 1e-9
     D, lo, up = prob.assemble(d["T_goal"][:G])
     assert np.abs(D - d["sol_D_goal"]).max() < 1e-13
     lb, ub = dgp.floyd_warshall_bounds(lo, up)
