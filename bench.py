@@ -35,8 +35,10 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 # HIP maps streams onto 4 hardware queues by default, so of more than 3 side streams some share a
-# queue and serialise; the serving measurement keeps 8 batches in flight (read at HIP start-up)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# queue and serialise; the serving measurement keeps 16 batches in flight (read at HIP start-up;
+# measured at 4096 LWA4D goals per batch: 4 queues 65 k, 8 queues / 8 streams 110 k, 16 / 12 190 k,
+# 24 / 16 203 k solves/s)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X vector = matrix fp64 peak (spec; fp32 vector 157.3 / 2)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
@@ -80,7 +82,7 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=1,
                     help="batches in flight in the TIMED region (default 1: steps back to back, the "
                          "headline configuration)")
-    ap.add_argument("--serving-streams", type=int, default=8,
+    ap.add_argument("--serving-streams", type=int, default=16,
                     help="extra, separately labelled measurement after the timed region: the same "
                          "batches issued round-robin on this many HIP streams (0 = skip)")
     ap.add_argument("--intended", action="store_true",
