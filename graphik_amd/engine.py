@@ -299,8 +299,9 @@ class Template:
     def _poses(self, T_goal):
         T = _dev(T_goal, self.device)
         B = T.shape[0]
-        T = T.reshape(B, -1).contiguous()         # [B][n_ee][(k+1)^2]
-        assert T.shape[1] == getattr(self, "n_ee", 1) * (self.k + 1) ** 2, T.shape
+        width = getattr(self, "n_ee", 1) * (self.k + 1) ** 2
+        assert T.numel() == B * width, (tuple(T.shape), width)
+        T = T.reshape(B, width).contiguous()      # [B][n_ee][(k+1)^2]
         return T, B
 
     def prepare(self, T_goal, return_K=False):

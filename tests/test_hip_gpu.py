@@ -1183,3 +1183,34 @@ def test_tree_robot_solve_batch(torch_cuda):
     assert set(q1) == {f"p{i}" for i in range(1, 6)}
     for i, e in enumerate(robot.end_effectors):
         assert np.linalg.norm(robot.pose(q1, e).trans - Tg[0, i][:3, 3]) < 1e-6
+
+
+def test_anchored_without_obstacles_agrees_with_reference_semantics(torch_cuda):
+    """With no obstacle the fixed-anchor formulation and the reference's quotient formulation
+    describe the same feasibility problem (the anchors' mutual distances are constants either way),
+    so on a bare UR10 both pipelines must reach the goal poses at the same rate, and -- UR10
+    solutions are isolated -- mostly on the same IK branch.  Also: B = 0, and a graph whose
+    obstacles were cleared."""
+    from graphik_amd.solvers.riemannian_solver import AnchoredProblem, solve_batch
+    robot, graph = make_graph("ur10")
+    ap = AnchoredProblem(graph)
+    assert len(ap.obstacles) == 0 and len(ap.free) == 10
+    rng = np.random.RandomState(13)
+    B = 512
+    lbq, ubq = robot.limits_arrays()
+    Tg = robot.fk_batch(lbq + (ubq - lbq) * rng.rand(B, robot.n))
+    r = ap.solve(Tg)
+    pos_a, rot_a = r["pos_err"].cpu().numpy(), r["rot_err"].cpu().numpy()
+    q_a = r["q"].cpu().numpy()
+    q_s, _, info = solve_batch(graph, Tg)
+    ok_a = (pos_a < 0.01) & (rot_a < 0.01)
+    ok_s = (info["pos_err"] < 0.01) & (info["rot_err"] < 0.01)
+    assert abs(ok_a.mean() - ok_s.mean()) < 0.05 and ok_a.mean() > 0.85, (ok_a.mean(), ok_s.mean())
+    both = ok_a & ok_s
+    assert np.median(pos_a[both]) < 2 * np.median(info["pos_err"][both]) + 1e-5
+    dq = np.abs(np.mod(q_a - q_s + np.pi, 2 * np.pi) - np.pi).max(axis=1)
+    assert np.mean(dq[both] < 1e-2) > 0.5          # same start point (robot-graph MDS), mostly the same branch
+    assert ap.solve(Tg[:0])["x"].shape[0] == 0
+    robot2, graph2 = make_graph("ur10_table")
+    graph2.clear_obstacles()
+    assert len(AnchoredProblem(graph2).obstacles) == 0
