@@ -137,6 +137,17 @@ def lib():
     """Load libgraphik_amd.so (raises if it has not been built: python -m graphik_amd.build)."""
     global _lib
     if _lib is None:
+        if "GIK_LIB_PATH" not in os.environ:
+            # never run against a binary that is older than its sources: rebuild when the toolchain
+            # is here (17 s), refuse otherwise
+            from . import build as _build
+            if os.path.exists(LIB_PATH) and _build._stale(LIB_PATH):
+                import shutil
+                if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+                    _build.build()
+                else:
+                    raise GikError(f"{LIB_PATH} was built from other sources than the ones in this tree "
+                                   "and there is no hipcc to rebuild it")
         if not os.path.exists(LIB_PATH):
             raise GikError(
                 f"HIP extension not built: {LIB_PATH} is missing. Run `python -m graphik_amd.build` "
