@@ -135,8 +135,10 @@ __device__ inline void stage_lds(double *tiles, uint32_t *meta, const uint32_t *
 // counter until the batch is exhausted.  Iteration counts differ by >50x between goals and the
 // hardware hands workgroups to XCDs round-robin, so a static block->problem map leaves whole
 // XCDs idle behind a few stragglers; the queue keeps every SIMD busy until the end.
+// (the fixed-anchor variant holds 34 KB of LDS per wave: four waves per CU, one per SIMD, so it may
+// as well have that SIMD's whole register file -- at two waves per SIMD it spilled into the hot loop)
 template <int K, int MAXDEG, bool THETA_ONE, bool ANCH = false>
-__global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
+__global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs a) {
   static_assert(!ANCH || K == 3, "the fixed-anchor formulation is 3-D");
   using Ctx = WaveCtx<K, MAXDEG, ANCH>;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -152,7 +154,7 @@ __global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
   if constexpr (ANCH) {
     // every target is a template constant here: records, pinned records and the constant rows of
     // the anchor table are staged once per wave; only the goal anchors change per problem
-    cx.init_anchored(a.an.obs_mask, a.an.obs, a.an.n_obs);
+    cx.init_anchored(a.an.obs_mask, a.an.obs, a.an.n_obs, !(a.dbg & 128));
     for (int t = lane; t < a.T; t += WAVE) sh_tgt[t] = a.targets[t];
     for (int t = lane; t < 4 * ANCH_MAXA; t += WAVE) cx.sh_anch[t] = a.an.anch_const[t];
     __builtin_amdgcn_wave_barrier();
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(WAVE, 2) rtr_wave_kernel(SolveArgs a) {
       if (lane < 3 * a.an.n_goal)
         cx.sh_anch[(a.an.goal_row0 + lane / 3) * 4 + lane % 3] =
             a.an.anchor_goal[(size_t)b * 3 * a.an.n_goal + lane];
-      __builtin_amdgcn_wave_barrier();
+      cx.obs_reset();
     } else {
       for (int t = lane; t < a.T; t += WAVE) sh_tgt[t] = a.targets[(size_t)b * a.T + t];
       __builtin_amdgcn_wave_barrier();
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
   Ctx cx;
   cx.init(lane, a.N, sh_tiles, sh_tgt, sh_meta);
   if constexpr (ANCH) {
-    cx.init_anchored(a.an.obs_mask, a.an.obs, a.an.n_obs);
+    cx.init_anchored(a.an.obs_mask, a.an.obs, a.an.n_obs, true);
     for (int t = lane; t < 4 * ANCH_MAXA; t += WAVE) cx.sh_anch[t] = a.an.anch_const[t];
     __builtin_amdgcn_wave_barrier();
     if (lane < 3 * a.an.n_goal)
