@@ -10,6 +10,22 @@
 // order), the four partial 3-vectors of a node are combined with two quad_perm DPP stages.
 // Reductions: per-wave MFMA reduction, then eight wave totals through a double-buffered LDS
 // scratch (one barrier per reduction).  The solver logic is the shared rtr_solve_one<>.
+//
+// Rigid cliques (k = 3).  The table scene's 5612 terms are 5565 equalities among 106 anchors (base,
+// goal nodes, obstacle centres: every pair is tied) and 47 others.  gik_template_create finds such
+// a clique A (n = |A| >= 16), gives its nodes the LDS rows 0..n-1 and takes its terms out of the
+// slot tables.  Their share of the Hessian-vector product is evaluated in closed form: with the
+// rows centred on the clique's centroid (y~_j, sum_j y~_j = 0) and the moments
+//   Sw = sum w_j, M = sum y~_j w_j^T, T3 = sum (y~_j.w_j) y~_j, U3 = sum |y~_j|^2 w_j   (18 sums),
+//   sum_j [2 (y_ij.w_ij) y_ij + c_ij w_ij]
+//     = 2 [ y~_i (n a_i - y~_i.Sw + tr M) + M y~_i + Syy w_i - T3 ]
+//       + w_i (n |y~_i|^2 + tr Syy - sum_j D_ij) - |y~_i|^2 Sw + 2 M^T y~_i - U3 + (D w)_i,
+// a_i = y~_i.w_i, Syy = sum y~_j y~_j^T (refreshed per accepted step).  Only (D w)_i is O(n) per
+// node, three FMAs per pair with D_ij held in registers (27 per thread at n = 106), instead of a
+// 20-instruction term evaluation from both ends.  The round-off is of the same size as the direct
+// sum's (both carry eps * |y|^2 |w| per pair: c_ij = d_ij - D_ij is a difference of O(1) numbers
+// either way; measured 2e-13 against 2e-13 relative to a long-double sum at n = 104).  Cost and
+// gradient (once per outer iteration) walk the clique pairs directly.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -22,6 +38,18 @@ namespace gik {
 constexpr int BLOCK_NT = 512;
 constexpr int BLOCK_WAVES = BLOCK_NT / WAVE;
 constexpr int BLOCK_MAXN = BLOCK_NT / 4;  // 128 nodes
+constexpr int CLQ_M = BLOCK_MAXN / 4;     // clique partners per thread (row 4m + part, m < CLQ_M)
+constexpr int CLQ_NMOM = 18;              // Sw[3], M[3][3], T3[3], U3[3]
+
+// launch-invariant tables of the workgroup-per-problem path (device pointers; gik_template_create)
+struct BlockTabs {
+  const int *nc_term;      // [Tc] index in the caller's target row of each slot-table term; null = identity
+  const int *clq_term;     // [M][512] target index of clique pair (row tid >> 2, row 4m + (tid & 3)); -1 = none
+  const int *node_of_row;  // [128] node (the caller's numbering) of each LDS row; null = identity
+  const int *wave_sl;      // [8][2] slot-loop bounds {SLE, SL} of each wavefront
+  int Tc;                  // terms kept in the slot tables
+  int n_clq;               // clique size (rows 0..n_clq-1), 0 = none
+};
 
 template <int K>
 struct BlockCtx {
@@ -34,7 +62,18 @@ struct BlockCtx {
   __device__ inline double ck_get(int i) const { return sh_ck[i * BLOCK_NT + tid]; }
 
   int tid, lane, wave, node, part, N, SL, SLE;  // slots [0, SLE) hold equality terms or padding only
-  bool active;       // owns an unknown: node < N && part < K
+  int gnode;         // the caller's index of LDS row `node`
+  bool live;         // LDS row `node` holds a node
+  bool active;       // owns an unknown: live && part < K
+  // rigid clique (rows 0..n_clq-1), k = 3 only
+  int n_clq, M_clq;
+  bool wclq;                   // this wavefront owns clique rows (wave-uniform)
+  uint32_t clq_valid;          // bit m: (node, 4m + part) is a clique pair
+  double Dr[CLQ_M];            // its squared target distance
+  double rD, n_count;          // sum_j D_ij of the node; (double)n_clq
+  double yt[3], ytp, y2t;      // centred row of the node, own entry, squared norm
+  double *sh_mom;              // [CLQ_NMOM][BLOCK_WAVES] per-wave partial moments, then
+                               // [8] Syy (xx xy xz yy yz zz), tr Syy, n of the committed point
   double *sh_Y;      // [128][4] accepted point
   double *sh_P;      // [128][4] proposal (cost) / point being committed
   double *sh_W;      // [128][4] direction being differentiated
@@ -48,31 +87,73 @@ struct BlockCtx {
 #endif
 
   __host__ __device__ static constexpr size_t lds_bytes(int T, int SL) {
-    return sizeof(double) * ((size_t)3 * BLOCK_MAXN * RS + (size_t)((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES) +
+    return sizeof(double) * ((size_t)3 * BLOCK_MAXN * RS + (size_t)((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES +
+                             CLQ_NMOM * BLOCK_WAVES + 8) +
            sizeof(uint32_t) * (size_t)SL * BLOCK_NT + (HAS_CK ? sizeof(double) * 4 * BLOCK_NT : 0);
   }
 
   __device__ inline bool lead() const { return tid == 0; }
 
-  __device__ inline void init(int N_, int SL_, int SLE_, double *base, const uint32_t *slots_lds, int T) {
+  // T: terms in the slot tables (bt.Tc); SL_: slot rows staged in LDS (the busiest wavefront's)
+  __device__ inline void init(int N_, int SL_, const BlockTabs &bt, double *base, const uint32_t *slots_lds,
+                              int T) {
     tid = threadIdx.x;
     lane = tid & 63;
     wave = tid >> 6;
     node = tid >> 2;
     part = tid & 3;
     N = N_;
-    SL = SL_;
-    SLE = SLE_;
-    active = node < N && part < K;
+    SLE = __builtin_amdgcn_readfirstlane(bt.wave_sl[2 * wave]);
+    SL = __builtin_amdgcn_readfirstlane(bt.wave_sl[2 * wave + 1]);
+    gnode = bt.node_of_row ? bt.node_of_row[node] : (node < N ? node : -1);
+    live = gnode >= 0;
+    active = live && part < K;
     sh_Y = base;
     sh_P = sh_Y + BLOCK_MAXN * RS;
     sh_W = sh_P + BLOCK_MAXN * RS;
     double *tg = sh_W + BLOCK_MAXN * RS;
     sh_tgt = tg;
     sh_red = tg + ((T + 1) & ~1);
+    sh_mom = sh_red + 2 * 8 * BLOCK_WAVES;
     sh_slots = slots_lds;
     sh_ck = reinterpret_cast<double *>(const_cast<uint32_t *>(slots_lds) + (size_t)SL_ * BLOCK_NT);
     red_buf = 0;
+    n_clq = (K == 3) ? bt.n_clq : 0;
+    M_clq = __builtin_amdgcn_readfirstlane((n_clq + 3) >> 2);
+    n_count = (double)n_clq;
+    wclq = __builtin_amdgcn_readfirstlane(wave * (WAVE / 4)) < n_clq;
+    clq_valid = 0u;
+    rD = 0.0;
+    if constexpr (K == 3) {
+#pragma unroll
+      for (int m = 0; m < CLQ_M; ++m) Dr[m] = 0.0;
+    }
+  }
+
+  // per problem: the slot-table targets into LDS (sh_tgt, writable alias `tgw`), the clique's
+  // target distances into registers
+  __device__ inline void load_problem(const double *tg_b, const BlockTabs &bt, double *tgw) {
+    for (int t = tid; t < bt.Tc; t += BLOCK_NT)
+      tgw[t] = tg_b ? tg_b[bt.nc_term ? bt.nc_term[t] : t] : 0.0;
+    if constexpr (K == 3) {
+      if (n_clq) {
+        double s = 0.0;
+        uint32_t v = 0u;
+#pragma unroll
+        for (int m = 0; m < CLQ_M; ++m) {
+          if (m >= M_clq) continue;
+          const int idx = bt.clq_term[m * BLOCK_NT + tid];
+          Dr[m] = (idx >= 0 && tg_b) ? tg_b[idx] : 0.0;
+          v |= (idx >= 0 ? 1u : 0u) << m;
+          s += Dr[m];
+        }
+        clq_valid = v;
+        s += dpp_f64<0xB1>(s);
+        s += dpp_f64<0x4E>(s);
+        rD = s;
+      }
+    }
+    __syncthreads();
   }
 
   template <int NV>
@@ -127,11 +208,11 @@ struct BlockCtx {
     if (active) sh_P[node * RS + part] = Yv;
     __syncthreads();
     double own[K];
-    row(sh_P, node < N ? node : 0, own);
+    row(sh_P, live ? node : 0, own);
     double f = 0.0;
     // equality-only slots first (no kind decoding: 5604 of the table scene's 5612 terms), then
     // the few slots that may hold hinge terms
-#pragma unroll 4
+#pragma unroll 2
     for (int s = 0; s < SLE; ++s) {
       const uint32_t m = sh_slots[s * BLOCK_NT + tid];
       double r[K];
@@ -163,17 +244,37 @@ struct BlockCtx {
       f = fma(wp * pp, pp, f);
       f = fma(wn * nn, nn, f);
     }
+    if constexpr (K == 3) {
+      if (n_clq && wclq) {   // clique pairs, each counted by its lower row
+        const double *pb = sh_P + part * RS;
+#pragma unroll
+        for (int m = 0; m < CLQ_M; ++m) {
+          if (m >= M_clq) continue;
+          double r[K];
+          row(pb, 4 * m, r);
+          double d = 0.0;
+#pragma unroll
+          for (int q = 0; q < K; ++q) {
+            const double y = own[q] - r[q];
+            d = fma(y, y, d);
+          }
+          const double u = Dr[m] - d;
+          const bool mine = ((clq_valid >> m) & 1u) && (4 * m + part > node);
+          f = fma(mine ? u : 0.0, u, f);
+        }
+      }
+    }
     return sum1(f);
   }
 
   // accept the point in sh_P: copy it to sh_Y and return this thread's egrad entry
   __device__ inline double commit() {
     double own[K];
-    row(sh_P, node < N ? node : 0, own);
+    row(sh_P, live ? node : 0, own);
     double acc[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = 0.0;
-#pragma unroll 4
+#pragma unroll 2
     for (int s = 0; s < SLE; ++s) {   // equality terms (padding: y = 0)
       const uint32_t m = sh_slots[s * BLOCK_NT + tid];
       double r[K], y[K];
@@ -206,10 +307,122 @@ struct BlockCtx {
 #pragma unroll
       for (int q = 0; q < K; ++q) acc[q] = fma(c, y[q], acc[q]);
     }
+    if constexpr (K == 3) {
+      if (n_clq && wclq) {
+        const double *pb = sh_P + part * RS;
+#pragma unroll
+        for (int m = 0; m < CLQ_M; ++m) {
+          if (m >= M_clq) continue;
+          double r[K], y[K];
+          row(pb, 4 * m, r);
+          double d = 0.0;
+#pragma unroll
+          for (int q = 0; q < K; ++q) {
+            y[q] = own[q] - r[q];
+            d = fma(y[q], y[q], d);
+          }
+          const double c = ((clq_valid >> m) & 1u) ? d - Dr[m] : 0.0;
+#pragma unroll
+          for (int q = 0; q < K; ++q) acc[q] = fma(c, y[q], acc[q]);
+        }
+      }
+    }
     const double G = 2.0 * quad_pick(acc);
     if (active) sh_Y[node * RS + part] = sh_P[node * RS + part];
     __syncthreads();
+    if constexpr (K == 3) {
+      if (n_clq) clique_refresh(own);
+    }
     return active ? G : 0.0;
+  }
+
+  // moments of the committed point over the clique: centroid, centred row of this node, Syy
+  __device__ inline void clique_refresh(const double (&own)[K]) {
+    const double lm = (node < n_clq && part == 0) ? 1.0 : 0.0;
+    double c[3] = {lm * own[0], lm * own[1], lm * own[2]};
+    sum_n<3>(c);
+    const double inv_n = 1.0 / n_count;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) yt[q] = fma(-c[q], inv_n, own[q]);
+    ytp = part == 0 ? yt[0] : (part == 1 ? yt[1] : yt[2]);
+    y2t = fma(yt[2], yt[2], fma(yt[1], yt[1], yt[0] * yt[0]));
+    double x[6] = {lm * yt[0] * yt[0], lm * yt[0] * yt[1], lm * yt[0] * yt[2],
+                   lm * yt[1] * yt[1], lm * yt[1] * yt[2], lm * yt[2] * yt[2]};
+    sum_n<6>(x);
+    if (tid == 0) {   // uniform; read back (broadcast) by clique_closed_form after the next barrier
+      double *cq = sh_mom + CLQ_NMOM * BLOCK_WAVES;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) cq[q] = x[q];
+      cq[6] = (x[0] + x[3]) + x[5];
+      cq[7] = n_count;
+    }
+  }
+
+  // Per-wave partial sums of the 18 clique moments of the direction W, from registers: thread
+  // (j, p < 3) holds w_j[p] and adds to {Sw[p], M[0][p], M[1][p], M[2][p], T3[p], U3[p]}.  One
+  // v_mfma_f64_4x4x4 with B = 1 adds the four 16-lane rows of every lane column and leaves, in
+  // lane row i, the totals of part i (layout: wave_sum_n, gik_wave.hip.h); two row rotations add
+  // the four quads of a row.  Lane 16 i then holds the wave's total for part i.
+  __device__ inline void clique_moment_partials(double W) {
+    if (!wclq) {
+      if ((lane & 15) == 0 && lane < 48) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) sh_mom[(r * 3 + (lane >> 4)) * BLOCK_WAVES + wave] = 0.0;
+      }
+      return;
+    }
+    const double cm = (node < n_clq && part < 3) ? 1.0 : 0.0;
+    const double w = cm * W;
+    double aw = ytp * w;
+    aw += dpp_f64<0xB1>(aw);
+    aw += dpp_f64<0x4E>(aw);   // a_j = y~_j . w_j in the four lanes of the node
+    double v[6] = {w, yt[0] * w, yt[1] * w, yt[2] * w, (cm * aw) * ytp, y2t * w};
+#pragma unroll
+    for (int r = 0; r < 6; ++r) v[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[r], 1.0, 0.0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) v[r] += dpp_f64<0x128>(v[r]);   // row_ror:8
+#pragma unroll
+    for (int r = 0; r < 6; ++r) v[r] += dpp_f64<0x124>(v[r]);   // row_ror:4
+    if ((lane & 15) == 0 && lane < 48) {
+      const int i = lane >> 4;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) sh_mom[(r * 3 + i) * BLOCK_WAVES + wave] = v[r];
+    }
+  }
+
+  // the O(1)-per-node part of the clique's Hessian-vector product (see the file header), entry
+  // `part` of node `node`; call after the barrier that publishes sh_W and sh_mom
+  __device__ inline double clique_closed_form(const double (&wi)[K]) {
+    static_assert(BLOCK_WAVES == 8, "eight partials per moment");
+    const double *p = sh_mom + (lane < CLQ_NMOM ? lane : 0) * BLOCK_WAVES;
+    const double2 p01 = *reinterpret_cast<const double2 *>(p), p23 = *reinterpret_cast<const double2 *>(p + 2);
+    const double2 p45 = *reinterpret_cast<const double2 *>(p + 4), p67 = *reinterpret_cast<const double2 *>(p + 6);
+    const double tot = ((p01.x + p01.y) + (p23.x + p23.y)) + ((p45.x + p45.y) + (p67.x + p67.y));
+    double mo[CLQ_NMOM];
+#pragma unroll
+    for (int q = 0; q < CLQ_NMOM; ++q) mo[q] = readlane_f64(tot, q);
+    // mo: Sw[c] = mo[c]; M[a][b] = mo[3 + 3a + b]; T3[c] = mo[12 + c]; U3[c] = mo[15 + c]
+    const double s_yw = (mo[3] + mo[7]) + mo[11];
+    const double a_i = fma(yt[2], wi[2], fma(yt[1], wi[1], yt[0] * wi[0]));
+    const double ySw = fma(yt[2], mo[2], fma(yt[1], mo[1], yt[0] * mo[0]));
+    const double *cq = sh_mom + CLQ_NMOM * BLOCK_WAVES;
+    const double2 c01 = *reinterpret_cast<const double2 *>(cq), c23 = *reinterpret_cast<const double2 *>(cq + 2);
+    const double2 c45 = *reinterpret_cast<const double2 *>(cq + 4), c67 = *reinterpret_cast<const double2 *>(cq + 6);
+    const double g = fma(c67.y, a_i, s_yw) - ySw;
+    const double cw = fma(c67.y, y2t, c67.x) - rD;
+    const double S[3][3] = {{c01.x, c01.y, c23.x}, {c01.y, c23.y, c45.x}, {c23.x, c45.x, c45.y}};
+    double h[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double My = fma(mo[3 + 3 * q + 2], yt[2], fma(mo[3 + 3 * q + 1], yt[1], mo[3 + 3 * q] * yt[0]));
+      const double Mty = fma(mo[9 + q], yt[2], fma(mo[6 + q], yt[1], mo[3 + q] * yt[0]));
+      const double Sw_ = fma(S[q][2], wi[2], fma(S[q][1], wi[1], S[q][0] * wi[0]));
+      const double G = fma(yt[q], g, My) + (Sw_ - mo[12 + q]);
+      const double C = fma(wi[q], cw, -(y2t * mo[q])) + (fma(2.0, Mty, -mo[15 + q]));
+      h[q] = fma(2.0, G, C);
+    }
+    const double hs = part == 0 ? h[0] : (part == 1 ? h[1] : h[2]);
+    return (node < n_clq && part < 3) ? hs : 0.0;
   }
 
   // ehess(Y, W) (lhess / jhess, costs.py:175-207, 39-58) at the committed point sh_Y
@@ -218,18 +431,67 @@ struct BlockCtx {
     const long long pt0 = __builtin_readcyclecounter();
 #endif
     if (active) sh_W[node * RS + part] = W;
+    if constexpr (K == 3) {
+      if (n_clq) clique_moment_partials(W);
+    }
     __syncthreads();
 #ifdef GIK_BLK_PROF
     const long long pt1 = __builtin_readcyclecounter();
 #endif
-    const int me = node < N ? node : 0;
+    const int me = live ? node : 0;
     double yi[K], wi[K];
     row(sh_Y, me, yi);
     row(sh_W, me, wi);
     double acc[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = 0.0;
-#pragma unroll 4
+    double hclq = 0.0;
+#ifdef GIK_BLK_PROF
+    long long pt1a = pt1, pt1b = pt1;
+#endif
+    if constexpr (K == 3) {
+      if (n_clq && wclq) {
+        hclq = clique_closed_form(wi);
+#ifdef GIK_BLK_PROF
+        pt1a = __builtin_readcyclecounter();
+#endif
+        // (D w)_i: partner rows 4m + part, a quarter of the clique per thread, in groups of four
+        // (Dr = 0 beyond the clique and rows up to 127 exist, so whole groups are run: one scalar
+        // branch per group).  The rows of group g + 1 are requested before the FMAs of group g,
+        // and two accumulator sets halve the dependent chains.
+        const double *wb = sh_W + part * RS;
+        double buf[2][4][K], acc1[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc1[q] = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row(wb, 4 * u, buf[0][u]);
+#pragma unroll
+        for (int g = 0; g < CLQ_M / 4; ++g) {
+          if (4 * g >= M_clq) continue;
+          if (g + 1 < CLQ_M / 4 && 4 * (g + 1) < M_clq) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) row(wb, 4 * (4 * (g + 1) + u), buf[(g + 1) & 1][u]);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+              if (u & 1)
+                acc1[q] = fma(Dr[4 * g + u], buf[g & 1][u][q], acc1[q]);
+              else
+                acc[q] = fma(Dr[4 * g + u], buf[g & 1][u][q], acc[q]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);   // do not hoist later groups' loads (registers)
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[q] += acc1[q];
+#ifdef GIK_BLK_PROF
+        pt1b = __builtin_readcyclecounter();
+#endif
+      }
+    }
+#pragma unroll 2
     for (int s = 0; s < SLE; ++s) {   // equality terms: always active (padding: y = w = 0)
       const uint32_t m = sh_slots[s * BLOCK_NT + tid];
       const int j = meta_j(m);
@@ -272,13 +534,15 @@ struct BlockCtx {
 #pragma unroll
       for (int q = 0; q < K; ++q) acc[q] = fma(a2s, y[q], fma(c, w[q], acc[q]));
     }
-    const double H = 2.0 * quad_pick(acc);
+    const double H = 2.0 * (quad_pick(acc) + hclq);
 #ifdef GIK_BLK_PROF
     if (prof && (tid & 63) == 0) {
       const long long pt2 = __builtin_readcyclecounter();
-      prof[8 + 3 * wave] += (double)(pt1 - pt0);
-      prof[9 + 3 * wave] += (double)(pt2 - pt1);
-      prof[10 + 3 * wave] += 1.0;
+      prof[8 + 6 * wave] += (double)(pt1 - pt0);     // store W, moment partials, barrier
+      prof[9 + 6 * wave] += (double)(pt1a - pt1);    // closed form
+      prof[10 + 6 * wave] += (double)(pt1b - pt1a);  // D w
+      prof[11 + 6 * wave] += (double)(pt2 - pt1b);   // slot loops, quad combine
+      prof[12 + 6 * wave] += 1.0;
     }
 #endif
     return active ? H : 0.0;
@@ -287,8 +551,8 @@ struct BlockCtx {
   // horizontal-space projector at the committed point (same algebra as WaveCtx::proj_setup)
   __device__ inline void proj_setup(int planar_proj_exact) {
     double own[K];
-    row(sh_Y, node < N ? node : 0, own);
-    const double lm = (node < N && part == 0) ? 1.0 : 0.0;
+    row(sh_Y, live ? node : 0, own);
+    const double lm = (live && part == 0) ? 1.0 : 0.0;
     const double am = active ? 1.0 : 0.0;
     if constexpr (K == 3) {
       const double y0 = own[0], y1 = own[1], y2 = own[2];

@@ -119,6 +119,7 @@ struct SolveArgs {
   int *q_ids;                      // [cap]
   unsigned int *q_seq;             // [cap], 0xffffffff = not published
   SliceState *q_state;             // [B]
+  BlockTabs bt;                    // workgroup-per-problem path
 };
 
 // Stage the launch-invariant slot table into LDS and zero the gather tiles (idle lanes and
@@ -271,6 +272,7 @@ struct KatArgs {
   int N, T, B, mode;      // 0 cost, 1 grad, 2 hess, 3 proj, 4 cost and grad (one pass)
   int planar_proj_exact;
   AnchArgs an;
+  BlockTabs bt;
 };
 
 template <int K, int MAXDEG, bool ANCH = false>
@@ -331,19 +333,21 @@ __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
 // workgroup-per-problem variants (graphs with N*k > 64)
 template <int K>
 __device__ inline uint32_t *block_stage(BlockCtx<K> &cx, double *smem, const uint32_t *g_slots, int N,
-                                        int T, int SL, int SLE) {
+                                        const BlockTabs &bt, int SL) {
   const int tid = threadIdx.x;
+  const int T = bt.Tc;
   for (int t = tid; t < 3 * BLOCK_MAXN * BlockCtx<K>::RS; t += BLOCK_NT) smem[t] = 0.0;
   double *tg = smem + 3 * BLOCK_MAXN * BlockCtx<K>::RS;
-  uint32_t *slots = reinterpret_cast<uint32_t *>(tg + ((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES);
+  uint32_t *slots =
+      reinterpret_cast<uint32_t *>(tg + ((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES + CLQ_NMOM * BLOCK_WAVES + 8);
   for (int s = 0; s < SL; ++s) slots[s * BLOCK_NT + tid] = g_slots[s * BLOCK_NT + tid];
-  cx.init(N, SL, SLE, smem, slots, T);
+  cx.init(N, SL, bt, smem, slots, T);
   __syncthreads();
   return slots;
 }
 
 template <int K>
-__global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL, int SLE) {
+__global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL) {
   // 16-byte alignment matters: the static `sh_b` below would otherwise push the dynamic segment
   // to offset 8, and every ds_read_b128 of a point row would be misaligned (measured 5x slower)
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -351,7 +355,7 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
   const int tid = threadIdx.x;
   const int NK = a.N * K;
   BlockCtx<K> cx;
-  block_stage<K>(cx, smem, a.slot_meta, a.N, a.T, SL, SLE);
+  block_stage<K>(cx, smem, a.slot_meta, a.N, a.bt, SL);
   double *sh_tgt = smem + 3 * BLOCK_MAXN * BlockCtx<K>::RS;
   for (;;) {
     if (tid == 0) {
@@ -363,22 +367,21 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
     const int b = sh_b, resumed = sh_resumed;
     __syncthreads();
     if (UNI(b < 0)) break;
-    for (int t = tid; t < a.T; t += BLOCK_NT) sh_tgt[t] = a.targets[(size_t)b * a.T + t];
-    __syncthreads();
+    cx.load_problem(a.targets + (size_t)b * a.T, a.bt, sh_tgt);
     RtrResume rs = {0.0, 0, 0, 0, 0, 0};
     double x = 0.0;
     if (resumed) {
       rs = load_slice_state(&a.q_state[b]);
-      if (cx.active) x = __builtin_nontemporal_load(&a.Y_out[(size_t)b * NK + cx.node * K + cx.part]);
+      if (cx.active) x = __builtin_nontemporal_load(&a.Y_out[(size_t)b * NK + cx.gnode * K + cx.part]);
     } else if (cx.active) {
-      x = a.Y_init[(size_t)b * NK + cx.node * K + cx.part];
+      x = a.Y_init[(size_t)b * NK + cx.gnode * K + cx.part];
     }
     RtrOut ro;
 #ifdef GIK_BLK_PROF
     cx.prof = ((a.dbg & 8) && b == 0) ? a.dbg_buf : nullptr;
 #endif
     rtr_solve_one<K, false, true>(cx, a.p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro, rs, a.slice_its);
-    if (cx.active) a.Y_out[(size_t)b * NK + cx.node * K + cx.part] = x;
+    if (cx.active) a.Y_out[(size_t)b * NK + cx.gnode * K + cx.part] = x;
     if (UNI(ro.paused)) {
       if (tid == 0) {
         SliceState st;
@@ -411,13 +414,13 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
 }
 
 template <int K>
-__global__ void __launch_bounds__(BLOCK_NT) rcg_block_kernel(SolveArgs a, int SL, int SLE) {
+__global__ void __launch_bounds__(BLOCK_NT) rcg_block_kernel(SolveArgs a, int SL) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ int sh_b;
   const int tid = threadIdx.x;
   const int NK = a.N * K;
   BlockCtx<K> cx;
-  block_stage<K>(cx, smem, a.slot_meta, a.N, a.T, SL, SLE);
+  block_stage<K>(cx, smem, a.slot_meta, a.N, a.bt, SL);
   double *sh_tgt = smem + 3 * BLOCK_MAXN * BlockCtx<K>::RS;
   for (;;) {
     if (tid == 0) sh_b = (int)atomicAdd(a.work_counter, 1u);
@@ -425,12 +428,11 @@ __global__ void __launch_bounds__(BLOCK_NT) rcg_block_kernel(SolveArgs a, int SL
     const int b = sh_b;
     __syncthreads();
     if (UNI(b >= a.B)) break;
-    for (int t = tid; t < a.T; t += BLOCK_NT) sh_tgt[t] = a.targets[(size_t)b * a.T + t];
-    __syncthreads();
-    double x = cx.active ? a.Y_init[(size_t)b * NK + cx.node * K + cx.part] : 0.0;
+    cx.load_problem(a.targets + (size_t)b * a.T, a.bt, sh_tgt);
+    double x = cx.active ? a.Y_init[(size_t)b * NK + cx.gnode * K + cx.part] : 0.0;
     RtrOut ro;
     rcg_solve_one<K>(cx, a.cg, a.trace, a.has_trace, b, x, ro);
-    if (cx.active) a.Y_out[(size_t)b * NK + cx.node * K + cx.part] = x;
+    if (cx.active) a.Y_out[(size_t)b * NK + cx.gnode * K + cx.part] = x;
     if (tid == 0) {
       gik_stats s;
       s.f = ro.f;
@@ -447,18 +449,16 @@ __global__ void __launch_bounds__(BLOCK_NT) rcg_block_kernel(SolveArgs a, int SL
 }
 
 template <int K>
-__global__ void __launch_bounds__(BLOCK_NT) kat_block_kernel(KatArgs a, int SL, int SLE) {
+__global__ void __launch_bounds__(BLOCK_NT) kat_block_kernel(KatArgs a, int SL) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const int NK = a.N * K;
   BlockCtx<K> cx;
-  block_stage<K>(cx, smem, a.slot_meta, a.N, a.T, SL, SLE);
+  block_stage<K>(cx, smem, a.slot_meta, a.N, a.bt, SL);
   double *sh_tgt = smem + 3 * BLOCK_MAXN * BlockCtx<K>::RS;
-  for (int t = tid; t < a.T; t += BLOCK_NT)
-    sh_tgt[t] = a.targets ? a.targets[(size_t)b * a.T + t] : 0.0;
-  __syncthreads();
-  const size_t at = (size_t)b * NK + cx.node * K + cx.part;
+  cx.load_problem(a.targets ? a.targets + (size_t)b * a.T : nullptr, a.bt, sh_tgt);
+  const size_t at = (size_t)b * NK + cx.gnode * K + cx.part;
   const double y = cx.active ? a.Y[at] : 0.0;
   const double w = (a.W && cx.active) ? a.W[at] : 0.0;
   const double f = cx.cost(y);
@@ -753,6 +753,7 @@ struct gik_template {
   bool is_block;  // workgroup-per-problem path
   int SL;         // slots per thread on the block path
   int SLE;        // ... of which the first SLE hold equality terms (or padding) only
+  gik::BlockTabs bt = {nullptr, nullptr, nullptr, nullptr, 0, 0};
   // device pre/post-processing (gik_pipeline_attach)
   bool has_pipe;
   gik::PipeConst pc;
@@ -854,6 +855,8 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   if (d->N < 2 || d->N > BLOCK_MAXN) return fail("N must be in [2, 128]");
   if (d->n_terms < 1 || d->n_terms > 65535) return fail("n_terms out of range");
   const int N = d->N, T = d->n_terms;
+  int dbg_eff = d->debug_flags;   // developer override, read once here (never inside a batch call)
+  if (const char *e = getenv("GIK_DBG")) dbg_eff = atoi(e);
   // per-node slot lists, in (neighbour, kind) order == the order the reference's edge loop
   // (row-major upper-triangle index pairs) accumulates into each row
   std::vector<std::vector<uint32_t>> slots(N);
@@ -883,31 +886,103 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     if (!var) is_block = true;   // a node busier than any wave variant: workgroup-per-problem path
   }
   if (is_block && ad) return fail("anchored templates need N * k <= 64 free unknowns and at most 20 terms per node");
+  // workgroup-per-problem tables (BlockTabs)
+  int n_clq = 0, Tc = T;
+  std::vector<int> nc_term, clq_term, node_of_row(BLOCK_MAXN, -1), wave_sl(2 * BLOCK_WAVES, 0);
   if (is_block) {
-    // four threads per node, a contiguous quarter of the node's terms each; within a thread the
-    // equality terms come first (slots [0, SLE): no kind decoding in the kernels) and the hinge
-    // terms last (slots [SLE, SL)); unused slots are inert padding (own node, kind 0, not owner)
-    std::vector<std::vector<Ent>> eqs(BLOCK_NT), hinges(BLOCK_NT);
-    int max_h = 0;
+    // A rigid clique -- a set of nodes every pair of which is tied by an equality term (the
+    // anchors of a scene with many obstacles) -- is taken out of the slot tables and handled in
+    // closed form (gik_block.hip.h).  Greedy by equality degree; rows 0..n_clq-1 of the LDS
+    // arrays are the clique's nodes in ascending order, the other nodes follow.
+    std::vector<int> eqterm((size_t)N * N, -1), deg(N, 0), order(N), row_of(N);
+    for (int t = 0; t < T; ++t) {
+      const int i = d->term_i[t], j = d->term_j[t];
+      if (d->term_kind[t] == GIK_TERM_EQ && eqterm[(size_t)i * N + j] < 0) {
+        eqterm[(size_t)i * N + j] = eqterm[(size_t)j * N + i] = t;
+        ++deg[i];
+        ++deg[j];
+      }
+    }
+    std::vector<char> in_clq(N, 0);
+    const int clique_min = (dbg_eff & 64) ? 4 : 16;
+    if (d->k == 3 && !(dbg_eff & 128)) {
+      for (int i = 0; i < N; ++i) order[i] = i;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return deg[a] > deg[b]; });
+      std::vector<int> A;
+      for (int v : order) {
+        bool all = true;
+        for (int a : A) all = all && eqterm[(size_t)v * N + a] >= 0;
+        if (all) A.push_back(v);
+      }
+      if ((int)A.size() >= clique_min) {
+        n_clq = (int)A.size();
+        for (int a : A) in_clq[a] = 1;
+      }
+    }
+    // with a clique the other nodes take the LAST rows (128 - F ...): their threads, the only
+    // ones with more than a slot or two, then sit in wavefronts that have no clique work
+    int r = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1 && n_clq) r = BLOCK_MAXN - (N - n_clq);
+      for (int i = 0; i < N; ++i)
+        if ((in_clq[i] != 0) == (pass == 0)) {
+          row_of[i] = r;
+          node_of_row[r++] = i;
+        }
+    }
+    // slot entries in row numbering, clique pairs left out; `term` = index in the LDS target table
+    ents.assign(BLOCK_MAXN, {});
+    for (int t = 0; t < T; ++t) {
+      const int i = d->term_i[t], j = d->term_j[t], kind = d->term_kind[t];
+      if (n_clq && kind == GIK_TERM_EQ && in_clq[i] && in_clq[j] && eqterm[(size_t)i * N + j] == t) continue;
+      const int ri = row_of[i], rj = row_of[j], tc = (int)nc_term.size();
+      nc_term.push_back(t);
+      ents[ri].push_back({rj, kind, tc, ri < rj ? 1 : 0});
+      ents[rj].push_back({ri, kind, tc, rj < ri ? 1 : 0});
+    }
+    Tc = (int)nc_term.size();
+    for (auto &e : ents)
+      std::stable_sort(e.begin(), e.end(), [](const Ent &a, const Ent &b) {
+        return a.j != b.j ? a.j < b.j : a.kind < b.kind;
+      });
+    const int M = (n_clq + 3) / 4;
+    clq_term.assign((size_t)std::max(M, 1) * BLOCK_NT, -1);
     for (int tid = 0; tid < BLOCK_NT; ++tid) {
-      const int node = tid >> 2, part = tid & 3;
-      const int deg = node < N ? (int)ents[node].size() : 0;
-      const int L = (deg + 3) / 4;
-      for (int e = part * L; e < std::min(deg, (part + 1) * L); ++e) {
+      const int row = tid >> 2, part = tid & 3;
+      for (int m = 0; m < M && row < n_clq; ++m) {
+        const int j = 4 * m + part;
+        if (j < n_clq && j != row)
+          clq_term[(size_t)m * BLOCK_NT + tid] = eqterm[(size_t)node_of_row[row] * N + node_of_row[j]];
+      }
+    }
+    // four threads per node, a contiguous quarter of the node's terms each; within a thread the
+    // equality terms come first (slots [0, SLE_w): no kind decoding in the kernels) and the hinge
+    // terms last (slots [SLE_w, SL_w)), with the bounds of the thread's wavefront w; unused
+    // slots are inert padding (own node, kind 0, not owner)
+    std::vector<std::vector<Ent>> eqs(BLOCK_NT), hinges(BLOCK_NT);
+    for (int tid = 0; tid < BLOCK_NT; ++tid) {
+      const int node = tid >> 2, part = tid & 3, w = tid / WAVE;
+      const int dg = (int)ents[node].size();
+      const int L = (dg + 3) / 4;
+      for (int e = part * L; e < std::min(dg, (part + 1) * L); ++e) {
         const Ent &en = ents[node][e];
         (en.kind == GIK_TERM_EQ ? eqs : hinges)[tid].push_back(en);
       }
-      SLE = std::max(SLE, (int)eqs[tid].size());
-      max_h = std::max(max_h, (int)hinges[tid].size());
+      wave_sl[2 * w] = std::max(wave_sl[2 * w], (int)eqs[tid].size());
+      wave_sl[2 * w + 1] = std::max(wave_sl[2 * w + 1], (int)hinges[tid].size());
     }
-    SL = SLE + max_h;
-    meta.assign((size_t)SL * BLOCK_NT, 0);
+    for (int w = 0; w < BLOCK_WAVES; ++w) {
+      wave_sl[2 * w + 1] += wave_sl[2 * w];   // {SLE_w, SL_w}
+      SLE = std::max(SLE, wave_sl[2 * w]);
+      SL = std::max(SL, wave_sl[2 * w + 1]);
+    }
+    meta.assign((size_t)std::max(SL, 1) * BLOCK_NT, 0);
     for (int tid = 0; tid < BLOCK_NT; ++tid) {
-      const int node = tid >> 2;
+      const int node = tid >> 2, sle = wave_sl[2 * (tid / WAVE)];
       for (int s = 0; s < SL; ++s) {
-        uint32_t m = meta_pack(node < N ? node : 0, 0, 0, 0);
-        const std::vector<Ent> &src = s < SLE ? eqs[tid] : hinges[tid];
-        const int e = s < SLE ? s : s - SLE;
+        uint32_t m = meta_pack(node_of_row[node] >= 0 ? node : 0, 0, 0, 0);
+        const std::vector<Ent> &src = s < sle ? eqs[tid] : hinges[tid];
+        const int e = s < sle ? s : s - sle;
         if (e < (int)src.size()) m = meta_pack(src[e].j, src[e].term, src[e].kind, src[e].owner);
         meta[(size_t)s * BLOCK_NT + tid] = m;
       }
@@ -955,18 +1030,17 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   t->cg.maxiter = d->maxiter;
   t->cg.beta_type = d->cg_beta_type;
   t->cg.planar_proj_exact = d->planar_proj_exact;
-  t->dbg = d->debug_flags;
+  t->dbg = dbg_eff;
   t->wpc_override = std::max(0, d->waves_per_cu);
   t->slice_its = d->slice_outer_its < 0 ? 256 : d->slice_outer_its;
   // developer overrides, read once here (never inside a batch call)
-  if (const char *e = getenv("GIK_DBG")) t->dbg = atoi(e);
   if (const char *e = getenv("GIK_WAVES_PER_CU")) t->wpc_override = std::max(1, atoi(e));
   if (const char *e = getenv("GIK_SLICE")) t->slice_its = std::max(0, atoi(e));
   t->d_slot_meta = nullptr;
   t->d_counters = nullptr;
   t->next_counter = 0;
   t->has_pipe = false;
-  t->smem_bytes = is_block ? (d->k == 3 ? BlockCtx<3>::lds_bytes(T, SL) : BlockCtx<2>::lds_bytes(T, SL))
+  t->smem_bytes = is_block ? (d->k == 3 ? BlockCtx<3>::lds_bytes(Tc, SL) : BlockCtx<2>::lds_bytes(Tc, SL))
                            : (ad ? var->lds_anch(T) : var->lds(T));
   if (is_block && t->smem_bytes > 160 * 1024) {
     delete t;
@@ -1057,10 +1131,24 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
                   "or device upload failed");
     }
   }
+  if (is_block) {
+    bool ok = true;
+    t->bt.nc_term = upload(t, nc_term.data(), nc_term.size(), ok);
+    t->bt.clq_term = upload(t, clq_term.data(), clq_term.size(), ok);
+    t->bt.node_of_row = upload(t, node_of_row.data(), node_of_row.size(), ok);
+    t->bt.wave_sl = upload(t, wave_sl.data(), wave_sl.size(), ok);
+    t->bt.Tc = Tc;
+    t->bt.n_clq = n_clq;
+    if (!ok) {
+      gik_template_destroy(t);
+      return fail("device upload of the workgroup-path tables failed");
+    }
+  }
   if (t->dbg & 32)
-      fprintf(stderr, "gik_template_create: N=%d k=%d T=%d %s maxdeg=%d lds=%zu B occupancy=%d per CU, %d CUs\n",
+      fprintf(stderr, "gik_template_create: N=%d k=%d T=%d %s maxdeg=%d lds=%zu B occupancy=%d per CU, %d CUs; "
+              "clique %d, slot terms %d, slots %d\n",
               t->N, t->K, t->T, is_block ? "block" : "wave", is_block ? 0 : t->variant->maxdeg,
-              t->smem_bytes, occ, t->n_cu);
+              t->smem_bytes, occ, t->n_cu, n_clq, Tc, SL);
   *out = t;
   return 0;
 }
@@ -1325,6 +1413,7 @@ static int launch_kat(const gik_template *t, int mode, const double *d_Y, const 
   KatArgs a;
   a.out_f = d_out_f;
   a.slot_meta = t->d_slot_meta;
+  a.bt = t->bt;
   a.targets = d_targets;
   a.Y = d_Y;
   a.W = d_W;
@@ -1350,10 +1439,10 @@ static int launch_kat(const gik_template *t, int mode, const double *d_Y, const 
   if (t->is_block) {
     if (t->K == 3)
       hipLaunchKernelGGL(kat_block_kernel<3>, dim3(B), dim3(BLOCK_NT), t->smem_bytes,
-                         (hipStream_t)stream, a, t->SL, t->SLE);
+                         (hipStream_t)stream, a, t->SL);
     else
       hipLaunchKernelGGL(kat_block_kernel<2>, dim3(B), dim3(BLOCK_NT), t->smem_bytes,
-                         (hipStream_t)stream, a, t->SL, t->SLE);
+                         (hipStream_t)stream, a, t->SL);
   } else {
     hipLaunchKernelGGL(t->variant->kat, dim3(B), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
   }
@@ -1397,6 +1486,7 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   if (!d_Y_init || !d_targets || !d_Y_out || !d_stats) return fail("null buffer");
   SolveArgs a;
   a.slot_meta = t->d_slot_meta;
+  a.bt = t->bt;
   a.targets = d_targets;
   a.Y_init = d_Y_init;
   a.Y_out = d_Y_out;
@@ -1484,11 +1574,10 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     HIP_OK(hipMemsetAsync(a.q_seq, 0xFF, cap * 4, (hipStream_t)stream));
   }
   if (t->is_block) {
-    void (*kern)(SolveArgs, int, int) =
+    void (*kern)(SolveArgs, int) =
         cg ? (t->K == 3 ? rcg_block_kernel<3> : rcg_block_kernel<2>)
            : (t->K == 3 ? rtr_block_kernel<3> : rtr_block_kernel<2>);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK_NT), t->smem_bytes, (hipStream_t)stream, a, t->SL,
-                       t->SLE);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK_NT), t->smem_bytes, (hipStream_t)stream, a, t->SL);
   } else {
     hipLaunchKernelGGL(t->anchored ? t->variant->solve_anch
                        : cg        ? t->variant->solve_cg

@@ -726,16 +726,21 @@ def test_device_pipeline_end_to_end(torch_cuda, name, B):
 
 
 # ---- workgroup-per-problem path (graphs with N*k > 64) -------------------------------------------
-@pytest.mark.parametrize("name", ["ur10_table", "lwa4d", "planar10_limits_halfpi"])
-def test_block_path_known_answers(torch_cuda, name):
+# debug_flags of the workgroup-per-problem path: 64 = closed form for rigid cliques from 4 nodes up
+# (default 16: the small robots' base + goal nodes then exercise it), 128 = closed form off
+@pytest.mark.parametrize("name,flags", [("ur10_table", 0), ("ur10_table", 128), ("lwa4d", 0), ("lwa4d", 64),
+                                        ("kuka", 64), ("planar10_limits_halfpi", 0)])
+def test_block_path_known_answers(torch_cuda, name, flags):
     """UR10 + table_environment(): 116 nodes, 5612 residual terms (BASELINE configs[2]) runs on
     the workgroup-per-problem kernels; the small graphs are forced onto the same kernels so both
-    code paths are checked against the same golden vectors."""
+    code paths are checked against the same golden vectors.  The table scene's 106 anchors form a
+    rigid clique whose Hessian-vector product is evaluated in closed form (gik_block.hip.h); the
+    same golden values pin it, and the direct sum (flags 128)."""
     from graphik_amd.engine import Template
     d = load_golden(name)
     use_lim = bool(int(d["use_limits"]))
     T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=int(d["dim"]),
-                               use_limits=use_lim, params={"force_block_path": 1})
+                               use_limits=use_lim, params={"force_block_path": 1, "debug_flags": flags})
     key = "lim" if use_lim else "nolim"
     tg = T.targets_from_D(d["D_goal"][0])
     Y, W = d["kat_Y"], d["kat_W"]
@@ -745,14 +750,15 @@ def test_block_path_known_answers(torch_cuda, name):
     assert rel_err(T.proj(Y, W).cpu().numpy(), d["kat_proj"]) < 1e-12
 
 
-@pytest.mark.parametrize("name", ["lwa4d", "planar10_limits_halfpi"])
-def test_block_path_trajectories_match_wave_path(torch_cuda, name):
+@pytest.mark.parametrize("name,flags", [("lwa4d", 0), ("lwa4d", 64), ("ur10", 64), ("planar10_limits_halfpi", 0)])
+def test_block_path_trajectories_match_wave_path(torch_cuda, name, flags):
     from graphik_amd.engine import Template
     d = load_golden(name)
     use_lim = bool(int(d["use_limits"]))
     kw = dict(k=int(d["dim"]), use_limits=use_lim)
     Tw = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], **kw)
-    Tb = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"force_block_path": 1}, **kw)
+    Tb = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"],
+                                params={"force_block_path": 1, "debug_flags": flags}, **kw)
     tg = Tw.targets_from_D(d["D_goal"])
     rw = Tw.solve(d["Y_init"], tg, trace_cap=16)
     rb = Tb.solve(d["Y_init"], tg, trace_cap=16)
@@ -763,6 +769,37 @@ def test_block_path_trajectories_match_wave_path(torch_cuda, name):
                        rb["trace"]["f_before"].cpu().numpy()[:, :m], rtol=1e-7)
     fw, fb = rw["f"].cpu().numpy(), rb["f"].cpu().numpy()
     assert np.array_equal(fw < 1e-9, fb < 1e-9)
+
+
+def test_clique_closed_form_against_direct_sum(torch_cuda):
+    """Table scene, random points and directions (not only the golden ones): the closed form of
+    the 106-anchor clique against the direct sum of the same kernel, cost / gradient / Hessian
+    product at 1e-12, near a solution too (where every c_ij of the clique is a difference of O(1)
+    numbers); the solves end in the same class with similar effort."""
+    from graphik_amd.engine import Template
+    d = load_golden("ur10_table")
+    kw = dict(k=3, use_limits=True)
+    Tc = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"debug_flags": 0}, **kw)
+    Td = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"debug_flags": 128}, **kw)
+    tg = Tc.targets_from_D(d["D_goal"])
+    G = len(tg)
+    rng = np.random.RandomState(3)
+    rd = Td.solve(d["Y_init"], tg)
+    rc = Tc.solve(d["Y_init"], tg)
+    xs = rd["x"].cpu().numpy()
+    for Y in (d["Y_init"], xs, xs + 1e-6 * rng.randn(*xs.shape), d["Y_init"] + 0.3 * rng.randn(*xs.shape)):
+        W = rng.randn(*Y.shape)
+        assert rel_err(Tc.cost(Y, tg).cpu().numpy(), Td.cost(Y, tg).cpu().numpy()) < 1e-12
+        gd = Td.grad(Y, tg).cpu().numpy()
+        assert np.abs(Tc.grad(Y, tg).cpu().numpy() - gd).max() < 1e-12 * max(1.0, np.abs(gd).max())
+        hd = Td.hess(Y, W, tg).cpu().numpy()
+        assert np.abs(Tc.hess(Y, W, tg).cpu().numpy() - hd).max() < 1e-12 * np.abs(hd).max()
+    fd, fc = rd["f"].cpu().numpy(), rc["f"].cpu().numpy()
+    assert np.array_equal(fd < 1e-9, fc < 1e-9)
+    itd, itc = rd["iterations"].cpu().numpy().astype(float), rc["iterations"].cpu().numpy().astype(float)
+    assert np.all(np.abs(itc / itd - 1.0) < 0.25), (itd, itc)
+    hvd, hvc = float(rd["inner_total"].sum()), float(rc["inner_total"].sum())
+    assert abs(hvc / hvd - 1.0) < 0.15, (hvd, hvc)
 
 
 def test_busy_nodes_fall_back_to_block_path(torch_cuda):
