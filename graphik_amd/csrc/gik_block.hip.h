@@ -261,6 +261,7 @@ struct BlockCtx {
           const double u = Dr[m] - d;
           const bool mine = ((clq_valid >> m) & 1u) && (4 * m + part > node);
           f = fma(mine ? u : 0.0, u, f);
+          if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight (registers)
         }
       }
     }
@@ -324,6 +325,7 @@ struct BlockCtx {
           const double c = ((clq_valid >> m) & 1u) ? d - Dr[m] : 0.0;
 #pragma unroll
           for (int q = 0; q < K; ++q) acc[q] = fma(c, y[q], acc[q]);
+          if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -388,6 +390,40 @@ struct BlockCtx {
 #pragma unroll
       for (int r = 0; r < 6; ++r) sh_mom[(r * 3 + i) * BLOCK_WAVES + wave] = v[r];
     }
+  }
+
+  __device__ inline void clique_dw(double (&acc)[K]) {
+    // (D w)_i: partner rows 4m + part, a quarter of the clique per thread, in groups of four
+    // (Dr = 0 beyond the clique and rows up to 127 exist, so whole groups are run: one scalar
+    // branch per group).  The rows of group g + 1 are requested before the FMAs of group g,
+    // and two accumulator sets halve the dependent chains.
+    const double *wb = sh_W + part * RS;
+    double buf[2][4][K], acc1[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc1[q] = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) row(wb, 4 * u, buf[0][u]);
+#pragma unroll
+    for (int g = 0; g < CLQ_M / 4; ++g) {
+      if (4 * g >= M_clq) continue;
+      if (g + 1 < CLQ_M / 4 && 4 * (g + 1) < M_clq) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row(wb, 4 * (4 * (g + 1) + u), buf[(g + 1) & 1][u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          if (u & 1)
+            acc1[q] = fma(Dr[4 * g + u], buf[g & 1][u][q], acc1[q]);
+          else
+            acc[q] = fma(Dr[4 * g + u], buf[g & 1][u][q], acc[q]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // do not hoist later groups' loads (registers)
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc[q] += acc1[q];
   }
 
   // the O(1)-per-node part of the clique's Hessian-vector product (see the file header), entry
@@ -455,37 +491,7 @@ struct BlockCtx {
 #ifdef GIK_BLK_PROF
         pt1a = __builtin_readcyclecounter();
 #endif
-        // (D w)_i: partner rows 4m + part, a quarter of the clique per thread, in groups of four
-        // (Dr = 0 beyond the clique and rows up to 127 exist, so whole groups are run: one scalar
-        // branch per group).  The rows of group g + 1 are requested before the FMAs of group g,
-        // and two accumulator sets halve the dependent chains.
-        const double *wb = sh_W + part * RS;
-        double buf[2][4][K], acc1[K];
-#pragma unroll
-        for (int q = 0; q < K; ++q) acc1[q] = 0.0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) row(wb, 4 * u, buf[0][u]);
-#pragma unroll
-        for (int g = 0; g < CLQ_M / 4; ++g) {
-          if (4 * g >= M_clq) continue;
-          if (g + 1 < CLQ_M / 4 && 4 * (g + 1) < M_clq) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) row(wb, 4 * (4 * (g + 1) + u), buf[(g + 1) & 1][u]);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int q = 0; q < K; ++q) {
-              if (u & 1)
-                acc1[q] = fma(Dr[4 * g + u], buf[g & 1][u][q], acc1[q]);
-              else
-                acc[q] = fma(Dr[4 * g + u], buf[g & 1][u][q], acc[q]);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);   // do not hoist later groups' loads (registers)
-        }
-#pragma unroll
-        for (int q = 0; q < K; ++q) acc[q] += acc1[q];
+        clique_dw(acc);
 #ifdef GIK_BLK_PROF
         pt1b = __builtin_readcyclecounter();
 #endif
