@@ -802,6 +802,55 @@ def test_clique_closed_form_against_direct_sum(torch_cuda):
     assert abs(hvc / hvd - 1.0) < 0.15, (hvd, hvc)
 
 
+@pytest.mark.parametrize("n_clique,n_other", [(21, 19), (16, 3), (45, 0), (106, 10)])
+def test_clique_detection_on_synthetic_graphs(torch_cuda, n_clique, n_other):
+    """Synthetic 3-D graphs on the workgroup path: a rigid clique whose size is not a multiple of
+    four, with lower / upper hinges ON TOP of some clique pairs (they stay in the slot tables), other
+    nodes chained to the clique and to each other, the clique's nodes scattered over the node
+    numbering -- cost, gradient and Hessian product against the CPU oracle at 1e-12, closed form and
+    direct sum, and one solve ending at the same cost."""
+    from oracle import c_oracle as co
+    from graphik_amd.engine import Template
+    rng = np.random.RandomState(11 + n_clique)
+    N = n_clique + n_other
+    P = rng.randn(N, 3) * np.array([1.0, 0.8, 0.5])
+    Dtrue = ((P[:, None] - P[None]) ** 2).sum(-1)
+    perm = rng.permutation(N)
+    clique, other = perm[:n_clique], perm[n_clique:]
+    om = np.zeros((N, N)); pL = np.zeros((N, N)); pU = np.zeros((N, N))
+    for a in range(n_clique):
+        for b in range(a + 1, n_clique):
+            i, j = clique[a], clique[b]
+            om[i, j] = om[j, i] = 1.0
+            if (a + b) % 11 == 0:        # hinges on a clique pair as well
+                pL[i, j] = pL[j, i] = 0.9 * Dtrue[i, j]
+                pU[i, j] = pU[j, i] = 1.2 * Dtrue[i, j]
+    for q, i in enumerate(other):
+        for j in list(clique[(3 * q) % n_clique:][:4]) + list(other[:q][-2:]):
+            if rng.rand() < 0.7:
+                om[i, j] = om[j, i] = 1.0
+            else:
+                pL[i, j] = pL[j, i] = 0.5 * Dtrue[i, j]
+                pU[i, j] = pU[j, i] = 1.5 * Dtrue[i, j]
+    il = co.limit_inds(om, pL, pU)
+    D = Dtrue * om
+    Y = P + 0.3 * rng.randn(N, 3)
+    W = rng.randn(N, 3)
+    want = (co.lcost(Y, D, om, pL, pU, il), co.lgrad(Y, D, om, pL, pU, il), co.lhess(Y, W, D, om, pL, pU, il))
+    fs = []
+    # (the largest case only fits the LDS with the clique taken out of the slot tables)
+    for flags in ((0, 128) if n_clique < 64 else (0,)):
+        T = Template.from_matrices(om, pL, pU, k=3, use_limits=True,
+                                   params={"force_block_path": 1, "debug_flags": flags})
+        tg = T.targets_from_D(D)
+        assert rel_err(float(T.cost(Y, tg)[0]), want[0]) < 1e-12
+        assert rel_err(T.grad(Y, tg)[0].cpu().numpy(), want[1]) < 1e-12
+        assert rel_err(T.hess(Y, W, tg)[0].cpu().numpy(), want[2]) < 1e-12
+        r = T.solve(Y[None], tg[None] if tg.ndim == 1 else tg)
+        fs.append(float(r["f"][0]))
+    assert max(fs) < 1e-9
+
+
 def test_busy_nodes_fall_back_to_block_path(torch_cuda):
     """A graph that fits a wavefront (N*k <= 64) but whose busiest node carries more residual
     terms than the largest compiled slot count is solved by the workgroup-per-problem kernels
@@ -915,7 +964,7 @@ def test_ur10_table_drop_in(torch_cuda):
 
 
 # ---- the reference's ConjugateGradient option (riemannian_solver.py:51-59) on the device --------
-@pytest.mark.parametrize("path", ["wave", "block"])
+@pytest.mark.parametrize("path", ["wave", "block", "block_clique"])
 @pytest.mark.parametrize("name", ["planar10_nolimits", "planar10_limits_halfpi", "lwa4d", "ur10"])
 def test_conjugate_gradient_against_oracle(torch_cuda, name, path):
     """rcg_wave_kernel / rcg_block_kernel against the CPU twin (which tests/test_oracle_golden.py
@@ -930,7 +979,11 @@ def test_conjugate_gradient_against_oracle(torch_cuda, name, path):
     d = load_golden(name)
     use_lim = bool(int(d["use_limits"]))
     planar = name.startswith("planar")
-    params = {"solver": "ConjugateGradient", "force_block_path": int(path == "block")}
+    params = {"solver": "ConjugateGradient", "force_block_path": int(path != "wave")}
+    if path == "block_clique":       # cost / gradient loops of the clique path (base + goal nodes)
+        if planar:
+            pytest.skip("the clique path is k = 3 only")
+        params["debug_flags"] = 64
     kw = {}
     if not planar:
         params["maxiter"] = kw["maxiter"] = int(cg["maxiter_3d"])
