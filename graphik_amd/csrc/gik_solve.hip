@@ -102,7 +102,9 @@ struct SolveArgs {
   int dbg;  // debug flags (env GIK_DBG): 1 = one block per problem, 2 = skip the TR loop,
             // 4 = dump (r_r, d_Hd, alpha, model) of every inner iteration of problem 0 to dbg_buf,
             // 8 = cycle counters of problem 0: dbg_buf = {cycles in tCG loops, tCG iterations, all cycles},
-            // 16 = rerun tCG after every rejected step instead of resuming from the checkpoint
+            // 16 = rerun tCG after every rejected step instead of resuming from the checkpoint;
+            // at template creation: 32 = print the kernel choice, 64 / 128 = clique closed form of the
+            // workgroup path from 4 nodes up / off
   double *dbg_buf;
   Params p;
   CgParams cg;   // solver == GIK_SOLVER_CONJUGATE_GRADIENT (rcg_* kernels)

@@ -74,7 +74,9 @@ typedef struct {
   int32_t slice_outer_its;   /* time slice of the workgroup-per-problem kernel in outer
                                 iterations; -1 = default (256), 0 = no time slicing            */
   int32_t debug_flags;       /* developer flags (gik_solve.hip: SolveArgs::dbg); 16 = rerun tCG
-                                after a rejected step instead of resuming from the checkpoint  */
+                                after a rejected step instead of resuming from the checkpoint;
+                                workgroup path: 64 = closed form for rigid cliques from 4 nodes
+                                up (default: 16 nodes), 128 = no closed form (direct sums)     */
   /* which of the reference's two solvers gik_solve_batch runs (riemannian_solver.py:40-65):
    * GIK_SOLVER_TRUST_REGIONS (default) or GIK_SOLVER_CONJUGATE_GRADIENT = pymanopt 0.2.5
    * ConjugateGradient + LineSearchAdaptive as configured at :51-59.  The CG defaults of
