@@ -964,8 +964,9 @@ def test_ur10_table_drop_in(torch_cuda):
 
 
 # ---- the reference's ConjugateGradient option (riemannian_solver.py:51-59) on the device --------
-@pytest.mark.parametrize("path", ["wave", "block", "block_clique"])
-@pytest.mark.parametrize("name", ["planar10_nolimits", "planar10_limits_halfpi", "lwa4d", "ur10"])
+@pytest.mark.parametrize("name,path", [(n, p) for n in ("planar10_nolimits", "planar10_limits_halfpi", "lwa4d", "ur10")
+                                       for p in ("wave", "block", "block_clique")
+                                       if not (p == "block_clique" and n.startswith("planar"))])   # clique path: k = 3
 def test_conjugate_gradient_against_oracle(torch_cuda, name, path):
     """rcg_wave_kernel / rcg_block_kernel against the CPU twin (which tests/test_oracle_golden.py
     pins to trajectories captured from the reference's own solve()): the first 12 iterations agree
@@ -981,8 +982,6 @@ def test_conjugate_gradient_against_oracle(torch_cuda, name, path):
     planar = name.startswith("planar")
     params = {"solver": "ConjugateGradient", "force_block_path": int(path != "wave")}
     if path == "block_clique":       # cost / gradient loops of the clique path (base + goal nodes)
-        if planar:
-            pytest.skip("the clique path is k = 3 only")
         params["debug_flags"] = 64
     kw = {}
     if not planar:
