@@ -519,17 +519,31 @@ __device__ inline void jacobi_blk(double *A, double *V, int N, int sweeps, doubl
       // column phase: A's and V's columns p, q of every row
       // (consecutive threads take the rotations of ONE row: its 2 np entries lie in a few cache
       // lines, whereas consecutive rows of one column are N doubles apart -- 64 lines per wave)
+      // (A and V in loops of their own: A may live in LDS, and each loop then has one address space)
       const int per = np * N;
-      for (int it = tid; it < 2 * per; it += PREP_NT) {
-        const int which = it >= per, rem = it - which * per, idx = rem / np, m = rem - idx * np;
-        double *M = which ? V : A;
+      for (int it = tid; it < per; it += PREP_NT) {
+        const int idx = it / np, m = it - idx * np;
         const int code = pq[m];
-        if (code >= 0 && M != nullptr) {
+        if (code >= 0) {
           const int p = code & 0xff, q = code >> 8;
           const double c = cs[2 * m], s = cs[2 * m + 1];
-          const double ap = M[idx * stride + p], aq = M[idx * stride + q];
-          M[idx * stride + p] = c * ap - s * aq;
-          M[idx * stride + q] = s * ap + c * aq;
+          const double ap = A[idx * stride + p], aq = A[idx * stride + q];
+          A[idx * stride + p] = c * ap - s * aq;
+          A[idx * stride + q] = s * ap + c * aq;
+        }
+      }
+      if (V != nullptr) {
+#pragma unroll 2
+        for (int it = tid; it < per; it += PREP_NT) {
+          const int idx = it / np, m = it - idx * np;
+          const int code = pq[m];
+          if (code >= 0) {
+            const int p = code & 0xff, q = code >> 8;
+            const double c = cs[2 * m], s = cs[2 * m + 1];
+            const double ap = V[idx * stride + p], aq = V[idx * stride + q];
+            V[idx * stride + p] = c * ap - s * aq;
+            V[idx * stride + q] = s * ap + c * aq;
+          }
         }
       }
       __syncthreads();
@@ -598,7 +612,13 @@ __device__ inline int count_eigs_above_blk(double *A, int N, double tau, double 
   return N - below;
 }
 
+// A_LDS: the N x N work matrix (Floyd-Warshall scratch, Gram matrix, Jacobi / Householder work
+// matrix, scatter matrix) lives in the dynamic LDS segment instead of the global slab -- the kernel
+// is bound by the L2 traffic of the Jacobi rounds, two thirds of which are A's (N <= 123: 8 N^2
+// bytes next to the 41 KB of static LDS)
+template <bool A_LDS>
 __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double *ws) {
+  extern __shared__ __attribute__((aligned(16))) double sh_A[];
   __shared__ double gd[2 * PREP_MAXA + 16];     // (several end effectors: checked at attach)
   __shared__ double cs[2 * (PREP_MAXN / 2)];
   __shared__ double ev[PREP_MAXN], sg[PREP_MAXN], red[PREP_NT / 64];
@@ -608,8 +628,8 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
   const int N = pc.N, K = pc.K, NN = N * N, tid = threadIdx.x;
   double *U = ws + (size_t)blockIdx.x * 5 * NN;  // upper bounds -> ub
   double *L = U + NN;                            // lower bounds
-  double *A = L + NN;                            // work matrix
-  double *V = A + NN;                            // eigenvectors / temp
+  double *A = A_LDS ? sh_A : L + NN;             // work matrix
+  double *V = L + 2 * NN;                        // eigenvectors / temp
   double *X = V + NN;                            // MDS factor
   const int D = K + 1;
 

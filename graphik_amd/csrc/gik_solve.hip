@@ -763,6 +763,7 @@ struct gik_template {
   size_t prep_smem;
   int prep_waves_per_cu = 8;   // resident prepare waves (workgroups on the block variant) per CU
   bool prep_block = false;
+  bool prep_a_lds = false;     // block variant: work matrix in LDS
   double *prep_ws = nullptr;   // [n_cu * prep_waves_per_cu][5][N*N] (block variant)
   hipEvent_t prep_done = nullptr;   // block variant: launches share prep_ws, so each one waits
   std::mutex prep_mutex;            // for the previous one (whatever stream it ran on)
@@ -1245,7 +1246,19 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
                   getenv("GIK_PREP_FORCE_BLOCK") != nullptr;
   if (t->prep_block) {
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prep_block_kernel, PREP_NT, 0) != hipSuccess)
+    // work matrix in LDS when it fits next to the kernel's static arrays (N <= 123), one workgroup per CU
+    t->prep_a_lds = false;
+    const size_t a_bytes = sizeof(double) * (size_t)N * N;
+    if (!getenv("GIK_PREP_A_GLOBAL") &&
+        hipFuncSetAttribute((const void *)prep_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)a_bytes) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prep_block_kernel<true>, PREP_NT, a_bytes) == hipSuccess &&
+        occ >= 1)
+      t->prep_a_lds = true;
+    else
+      (void)hipGetLastError();
+    if (!t->prep_a_lds &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prep_block_kernel<false>, PREP_NT, 0) != hipSuccess)
       occ = 1;
     occ = std::max(1, std::min(occ, 2));   // 5 N^2 doubles per workgroup: keep the slabs cache-resident
     if (const char *e = getenv("GIK_PREP_WAVES_PER_CU")) occ = std::max(1, atoi(e));
@@ -1301,8 +1314,12 @@ int gik_prepare_batch_debug(const gik_template *t, const double *d_T_goal, int B
     gik_template *mt = const_cast<gik_template *>(t);   // the workspace hand-over is the mutable part
     std::lock_guard<std::mutex> lock(mt->prep_mutex);
     if (mt->prep_pending) HIP_OK(hipStreamWaitEvent((hipStream_t)stream, mt->prep_done, 0));
-    hipLaunchKernelGGL(prep_block_kernel, dim3(grid), dim3(PREP_NT), 0, (hipStream_t)stream, a,
-                       t->prep_ws);
+    if (t->prep_a_lds)
+      hipLaunchKernelGGL(prep_block_kernel<true>, dim3(grid), dim3(PREP_NT),
+                         sizeof(double) * (size_t)t->N * t->N, (hipStream_t)stream, a, t->prep_ws);
+    else
+      hipLaunchKernelGGL(prep_block_kernel<false>, dim3(grid), dim3(PREP_NT), 0, (hipStream_t)stream, a,
+                         t->prep_ws);
     HIP_OK(hipEventRecord(mt->prep_done, (hipStream_t)stream));
     mt->prep_pending = true;
   } else
