@@ -772,6 +772,28 @@ struct gik_template {
 };
 static constexpr int kCounterRing = 256;
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a launch: several
+// templates share a kernel, so the allowance is only ever raised (a later, smaller template must
+// not take it away from an earlier one).
+static hipError_t raise_dynamic_lds(const void *fn, size_t bytes) {
+  struct Grant { const void *fn; int device; size_t bytes; };
+  static std::mutex mu;
+  static std::vector<Grant> granted;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  for (Grant &g : granted)
+    if (g.fn == fn && g.device == dev) {
+      if (g.bytes >= bytes) return hipSuccess;
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e == hipSuccess) g.bytes = bytes;
+      return e;
+    }
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) granted.push_back({fn, dev, bytes});
+  return e;
+}
+
 template <typename T>
 static const T *upload(gik_template *t, const T *host, size_t count, bool &ok) {
   if (count == 0 || !host) return nullptr;
@@ -1059,8 +1081,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     const void *fns[2] = {solve_kernel, d->k == 3 ? (const void *)kat_block_kernel<3>
                                                   : (const void *)kat_block_kernel<2>};
     for (const void *fn : fns) {
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)t->smem_bytes) != hipSuccess) {
+      if (raise_dynamic_lds(fn, t->smem_bytes) != hipSuccess) {
         (void)hipGetLastError();
         const std::string msg =
             "cannot reserve " + std::to_string(t->smem_bytes) + " bytes of LDS per workgroup";
@@ -1250,8 +1271,7 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
     t->prep_a_lds = false;
     const size_t a_bytes = sizeof(double) * (size_t)N * N;
     if (!getenv("GIK_PREP_A_GLOBAL") &&
-        hipFuncSetAttribute((const void *)prep_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)a_bytes) == hipSuccess &&
+        raise_dynamic_lds((const void *)prep_block_kernel<true>, a_bytes) == hipSuccess &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prep_block_kernel<true>, PREP_NT, a_bytes) == hipSuccess &&
         occ >= 1)
       t->prep_a_lds = true;

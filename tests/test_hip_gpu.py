@@ -677,6 +677,30 @@ def test_block_prepare_kernel_equals_wave_kernel(torch_cuda, monkeypatch, name):
         assert np.array_equal(a, b)
 
 
+def test_lds_allowance_survives_later_templates(torch_cuda):
+    """The dynamic-LDS allowance is a property of a kernel, not of a launch: a template that needs
+    less (LWA4D on the workgroup kernels: 3 KB work matrix, 10 KB of solver state) created AFTER one
+    that needs more (table scene: 105 KB work matrix in the prepare kernel) must not take it away."""
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    robot, graph = make_graph("ur10_table")
+    rng = np.random.RandomState(2)
+    lb_q, ub_q = robot.limits_arrays()
+    Tg = robot.fk_batch(lb_q + (ub_q - lb_q) * rng.rand(8, robot.n))
+    big = BatchProblem(graph, use_limits=True)
+    before = [x.cpu().numpy() for x in big.template.prepare(Tg)]
+    r0 = big.template.solve(before[1], before[0])["x"].cpu().numpy()
+    robot2, graph2 = make_graph("lwa4d")
+    small = BatchProblem(graph2, use_limits=True, force_block_prepare=True, params={"force_block_path": 1})
+    lb2, ub2 = robot2.limits_arrays()
+    Tg2 = robot2.fk_batch(lb2 + (ub2 - lb2) * rng.rand(8, robot2.n))
+    tg2, Y2 = small.template.prepare(Tg2)
+    assert np.all(np.isfinite(small.template.solve(Y2, tg2)["x"].cpu().numpy()))
+    after = [x.cpu().numpy() for x in big.template.prepare(Tg)]
+    for a, b in zip(before, after):
+        assert np.array_equal(a, b)
+    assert np.array_equal(r0, big.template.solve(after[1], after[0])["x"].cpu().numpy())
+
+
 @pytest.mark.parametrize("name", ["lwa4d", "ur10", "kuka", "planar10_limits_halfpi"])
 def test_device_recover_matches_host(torch_cuda, name):
     from graphik_amd.solvers.riemannian_solver import BatchProblem
