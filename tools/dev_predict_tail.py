@@ -1,0 +1,124 @@
+"""dev: can the long problems of a batch be told apart after a short probe?  Solve every goal with
+maxiter = P (probe), then fully; rank by what the probe saw (f, gradnorm, trust radius is not
+visible) and report how many of the `maxiter` goals / of the total work the top-S predictions
+hold, and simulated makespans: first come first served vs longest-predicted-first after the probe.
+Usage: dev_predict_tail.py robot B [probe ...]"""
+import os, sys
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+from conftest import make_graph
+from graphik_amd.solvers.riemannian_solver import BatchProblem
+from graphik_amd.engine import Template
+
+name, B = sys.argv[1], int(sys.argv[2])
+probes = [int(x) for x in sys.argv[3:]] or [40, 80, 160]
+robot, graph = make_graph(name)
+rng = np.random.RandomState(0)
+lb, ub = robot.limits_arrays()
+Tg = torch.from_numpy(robot.fk_batch(lb + (ub - lb) * rng.rand(B, robot.n))).cuda()
+prob = BatchProblem(graph, use_limits=True)
+tg, Y0 = prob.template.prepare(Tg)
+full = prob.template.solve(Y0, tg)
+work = full["inner_executed"].cpu().numpy().astype(float) + 8.0 * full["iterations"].cpu().numpy()   # ~cycles / 972
+its = full["iterations"].cpu().numpy()
+maxit = its >= 3000
+print(f"{name} B={B}: maxiter {maxit.mean():.4f}, total work {work.sum():.3g}, max {work.max():.3g}, mean {work.mean():.3g}")
+S = 1024   # SIMDs
+
+def simulate(order, work, slots=2, slow=1.35):
+    """list scheduling on S SIMDs with `slots` waves each; a wave runs at 1/slow when its SIMD has
+    two busy waves.  Event-driven, work in product units."""
+    import heapq
+    n = len(order); nxt = 0
+    rem = {}   # wave id -> remaining work
+    simd_busy = [[] for _ in range(S)]
+    t = 0.0
+    # fill
+    active = []
+    for s in range(S):
+        for k in range(slots):
+            if nxt < n:
+                simd_busy[s].append([work[order[nxt]], nxt]); nxt += 1
+    while True:
+        # next completion
+        best = None
+        for s in range(S):
+            m = len(simd_busy[s])
+            if m == 0: continue
+            rate = 1.0 if m == 1 else 1.0 / slow
+            for w in simd_busy[s]:
+                dt = w[0] / rate
+                if best is None or dt < best[0]: best = (dt, s, w)
+        if best is None: break
+        dt = best[0]; t += dt
+        for s in range(S):
+            m = len(simd_busy[s])
+            if m == 0: continue
+            rate = 1.0 if m == 1 else 1.0 / slow
+            for w in simd_busy[s]: w[0] -= dt * rate
+        s = best[1]
+        simd_busy[s] = [w for w in simd_busy[s] if w[0] > 1e-9]
+        while len(simd_busy[s]) < slots and nxt < n:
+            simd_busy[s].append([work[order[nxt]], nxt]); nxt += 1
+    return t
+
+def fast_sim(order, w, slots=2, slow=1.35):
+    """same model, vectorised over SIMDs per event batch (approximate: processes completions in time order)"""
+    import heapq
+    n = len(order); nxt = 0
+    # state per SIMD: list of remaining works
+    simd = [[] for _ in range(S)]
+    for s in range(S):
+        for k in range(slots):
+            if nxt < n: simd[s].append(w[order[nxt]]); nxt += 1
+    # each SIMD evolves independently between claims: claims only depend on global order -> event queue of SIMD next-completion times
+    tnow = [0.0] * S
+    def next_done(s):
+        m = len(simd[s])
+        if m == 0: return None
+        rate = 1.0 if m == 1 else 1.0 / slow
+        return tnow[s] + min(simd[s]) / rate
+    heap = []
+    for s in range(S):
+        nd = next_done(s)
+        if nd is not None: heapq.heappush(heap, (nd, s))
+    tend = 0.0
+    while heap:
+        t, s = heapq.heappop(heap)
+        m = len(simd[s])
+        rate = 1.0 if m == 1 else 1.0 / slow
+        dt = t - tnow[s]
+        simd[s] = [x - dt * rate for x in simd[s]]
+        tnow[s] = t
+        simd[s] = [x for x in simd[s] if x > 1e-6]
+        while len(simd[s]) < slots and nxt < n:
+            simd[s].append(w[order[nxt]]); nxt += 1
+        tend = max(tend, t)
+        nd = next_done(s)
+        if nd is not None: heapq.heappush(heap, (nd, s))
+    return tend
+
+cyc = 972 / 2.4e6   # ms per product-unit
+fcfs = fast_sim(np.arange(B), work)
+lpt = fast_sim(np.argsort(-work), work)
+print(f"simulated makespan: FCFS {fcfs * cyc:.1f} ms, clairvoyant longest-first {lpt * cyc:.1f} ms, lower bound max(job, total/S) {max(work.max(), work.sum() / S) * cyc:.1f} ms")
+for P in probes:
+    T = Template.from_matrices(prob.omega, prob.psi_L, prob.psi_U, k=3, use_limits=True, params={"maxiter": P})
+    pr = T.solve(Y0, tg)
+    f = pr["f"].cpu().numpy(); gn = pr["gradnorm"].cpu().numpy(); done = pr["iterations"].cpu().numpy() < P
+    spent = pr["inner_executed"].cpu().numpy().astype(float) + 8.0 * pr["iterations"].cpu().numpy()
+    rest = np.maximum(work - spent, 0.0)
+    for label, key in (("f", f), ("gradnorm", gn), ("f*gn", f * gn)):
+        key = np.where(done, -1.0, key)
+        order = np.argsort(-key)
+        top = order[:S]
+        cap_max = maxit[top].sum() / max(1, maxit.sum())
+        cap_work = rest[top].sum() / rest.sum()
+        from scipy.stats import spearmanr
+        rho = spearmanr(key[~done], rest[~done]).correlation
+        # two-phase: probe phase (all problems, P iterations, FCFS) then predicted-longest-first on the rest
+        t1 = fast_sim(np.arange(B), spent)
+        t2 = fast_sim(order[: int((~done).sum())], rest)
+        print(f"probe {P:4d} key {label:9s}: unfinished {1 - done.mean():.3f}, probe work {spent.sum() / work.sum():.3f} of total; Spearman(key, rest) {rho:.2f}; "
+              f"top-{S} holds {cap_max:.3f} of the maxiter goals, {cap_work:.3f} of the remaining work; two-phase makespan {(t1 + t2) * cyc:.1f} ms")
