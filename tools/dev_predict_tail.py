@@ -26,45 +26,9 @@ maxit = its >= 3000
 print(f"{name} B={B}: maxiter {maxit.mean():.4f}, total work {work.sum():.3g}, max {work.max():.3g}, mean {work.mean():.3g}")
 S = 1024   # SIMDs
 
-def simulate(order, work, slots=2, slow=1.35):
-    """list scheduling on S SIMDs with `slots` waves each; a wave runs at 1/slow when its SIMD has
-    two busy waves.  Event-driven, work in product units."""
-    import heapq
-    n = len(order); nxt = 0
-    rem = {}   # wave id -> remaining work
-    simd_busy = [[] for _ in range(S)]
-    t = 0.0
-    # fill
-    active = []
-    for s in range(S):
-        for k in range(slots):
-            if nxt < n:
-                simd_busy[s].append([work[order[nxt]], nxt]); nxt += 1
-    while True:
-        # next completion
-        best = None
-        for s in range(S):
-            m = len(simd_busy[s])
-            if m == 0: continue
-            rate = 1.0 if m == 1 else 1.0 / slow
-            for w in simd_busy[s]:
-                dt = w[0] / rate
-                if best is None or dt < best[0]: best = (dt, s, w)
-        if best is None: break
-        dt = best[0]; t += dt
-        for s in range(S):
-            m = len(simd_busy[s])
-            if m == 0: continue
-            rate = 1.0 if m == 1 else 1.0 / slow
-            for w in simd_busy[s]: w[0] -= dt * rate
-        s = best[1]
-        simd_busy[s] = [w for w in simd_busy[s] if w[0] > 1e-9]
-        while len(simd_busy[s]) < slots and nxt < n:
-            simd_busy[s].append([work[order[nxt]], nxt]); nxt += 1
-    return t
-
 def fast_sim(order, w, slots=2, slow=1.35):
-    """same model, vectorised over SIMDs per event batch (approximate: processes completions in time order)"""
+    """List scheduling on S SIMDs with `slots` waves each, problems claimed in `order`; a wave runs at
+    1 / slow of its speed while its SIMD has two busy waves.  Event-driven; work in product units."""
     import heapq
     n = len(order); nxt = 0
     # state per SIMD: list of remaining works
@@ -72,7 +36,6 @@ def fast_sim(order, w, slots=2, slow=1.35):
     for s in range(S):
         for k in range(slots):
             if nxt < n: simd[s].append(w[order[nxt]]); nxt += 1
-    # each SIMD evolves independently between claims: claims only depend on global order -> event queue of SIMD next-completion times
     tnow = [0.0] * S
     def next_done(s):
         m = len(simd[s])
