@@ -25,6 +25,7 @@ its = full["iterations"].cpu().numpy()
 maxit = its >= 3000
 print(f"{name} B={B}: maxiter {maxit.mean():.4f}, total work {work.sum():.3g}, max {work.max():.3g}, mean {work.mean():.3g}")
 S = 1024   # SIMDs
+cyc = 972 / 2.4e6   # ms per product-unit
 
 def fast_sim(order, w, slots=2, slow=1.35):
     """List scheduling on S SIMDs with `slots` waves each, problems claimed in `order`; a wave runs at
@@ -62,9 +63,15 @@ def fast_sim(order, w, slots=2, slow=1.35):
         if nd is not None: heapq.heappush(heap, (nd, s))
     return tend
 
-cyc = 972 / 2.4e6   # ms per product-unit
 fcfs = fast_sim(np.arange(B), work)
 lpt = fast_sim(np.argsort(-work), work)
+# ideal processor sharing (every unfinished problem advances at the same rate, at most one SIMD
+# each): the service level s grows at min(1, S / n(s)), n(s) = number of problems longer than s
+ws = np.sort(work)
+edges = np.concatenate(([0.0], ws))
+n_longer = len(ws) - np.arange(len(ws))          # problems longer than edges[k], k = 0..n-1
+t_ps = float(np.sum(np.diff(edges) * np.maximum(n_longer / S, 1.0)))
+print(f"ideal processor sharing (time slicing with migration, no overhead): {t_ps * cyc:.1f} ms")
 print(f"simulated makespan: FCFS {fcfs * cyc:.1f} ms, clairvoyant longest-first {lpt * cyc:.1f} ms, lower bound max(job, total/S) {max(work.max(), work.sum() / S) * cyc:.1f} ms")
 for P in probes:
     T = Template.from_matrices(prob.omega, prob.psi_L, prob.psi_U, k=3, use_limits=True, params={"maxiter": P})
