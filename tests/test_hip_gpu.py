@@ -402,7 +402,8 @@ def test_checkpoint_resume_is_bit_identical(torch_cuda, monkeypatch, name):
     assert a["inner_executed"].sum() < 0.95 * b["inner_executed"].sum()   # measured: -11 ... -14 %
 
 
-def test_time_slicing_is_bit_identical(torch_cuda, monkeypatch):
+@pytest.mark.parametrize("flags", [0, 64])     # 64: with the clique closed form (base + goal nodes)
+def test_time_slicing_is_bit_identical(torch_cuda, monkeypatch, flags):
     """The workgroup-per-problem kernel re-queues a problem that has not met a stopping rule after
     slice_outer_its outer iterations (default 256) behind everything that is waiting, so that the long
     problems of a batch do not start last.  A solve is exactly resumable from (x, Delta,
@@ -419,7 +420,8 @@ def test_time_slicing_is_bit_identical(torch_cuda, monkeypatch):
     runs = {}
     for sl in ("0", "256", "24"):
         tpl = Template.from_matrices(prob.omega, prob.psi_L, prob.psi_U, k=3, use_limits=True,
-                                     params={"force_block_path": 1, "slice_outer_its": int(sl)})
+                                     params={"force_block_path": 1, "slice_outer_its": int(sl),
+                                             "debug_flags": flags})
         r = tpl.solve(Y0, targets, trace_cap=40)
         runs[sl] = {k: r[k].cpu().numpy() for k in keys + ("inner_executed",)}
         runs[sl]["numit"] = r["trace"]["numit"].cpu().numpy()
