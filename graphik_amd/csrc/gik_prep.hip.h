@@ -455,9 +455,10 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // prep_block_kernel: the same pre-processing for graphs beyond one wavefront's LDS (N <= 128, up to
-// 256 anchors: UR10 + table_environment(), N = 116): one 512-thread workgroup per goal, the five
-// N x N matrices in a per-workgroup slab of global memory (L2 / Infinity-Cache resident), the small
-// vectors in LDS.  Same operations in the same order per matrix element as prep_wave_kernel -- the
+// 256 anchors: UR10 + table_environment(), N = 116): one 512-thread workgroup per goal, the
+// N x N matrices in a per-workgroup slab of global memory (L2 / Infinity-Cache resident) except the
+// one being worked on, which sits in LDS when it fits (prep_block_kernel<true>), the small vectors
+// in LDS.  Same operations in the same order per matrix element as prep_wave_kernel -- the
 // rotations of a Jacobi round act on disjoint index pairs, every other phase is element-wise -- so
 // on a graph both kernels can take the results agree bit for bit (tests).
 constexpr int PREP_NT = 512;
@@ -612,10 +613,10 @@ __device__ inline int count_eigs_above_blk(double *A, int N, double tau, double 
   return N - below;
 }
 
-// A_LDS: the N x N work matrix (Floyd-Warshall scratch, Gram matrix, Jacobi / Householder work
-// matrix, scatter matrix) lives in the dynamic LDS segment instead of the global slab -- the kernel
-// is bound by the L2 traffic of the Jacobi rounds, two thirds of which are A's (N <= 123: 8 N^2
-// bytes next to the 41 KB of static LDS)
+// A_LDS: the matrix being worked on (the upper bounds during the N Floyd-Warshall rounds, then the
+// Gram matrix = Jacobi / Householder work matrix, then the scatter matrix) lives in the dynamic LDS
+// segment instead of the global slab -- the kernel is bound by the L2 traffic of the Jacobi rounds,
+// two thirds of which are the work matrix's (N <= 123: 8 N^2 bytes next to the 41 KB of static LDS)
 template <bool A_LDS>
 __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double *ws) {
   extern __shared__ __attribute__((aligned(16))) double sh_A[];
@@ -626,9 +627,14 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
   __shared__ double dl[PREP_PC * PREP_MAXN];    // edge differences of PREP_PC pairs
   const PipeConst &pc = a.pc;
   const int N = pc.N, K = pc.K, NN = N * N, tid = threadIdx.x;
-  double *U = ws + (size_t)blockIdx.x * 5 * NN;  // upper bounds -> ub
-  double *L = U + NN;                            // lower bounds
-  double *A = A_LDS ? sh_A : L + NN;             // work matrix
+  double *Ug = ws + (size_t)blockIdx.x * 5 * NN;
+  double *L = Ug + NN;                           // lower bounds
+  double *Ag = L + NN;
+  // the LDS buffer holds the upper bounds during bound smoothing (N Floyd-Warshall rounds over the
+  // whole matrix) and becomes the work matrix once the Gram matrix is formed
+  double *U = A_LDS ? sh_A : Ug;                 // upper bounds -> ub
+  double *A1 = Ag;                               // max-plus intermediate
+  double *A = A_LDS ? sh_A : Ag;                 // work matrix (from the Gram matrix on)
   double *V = L + 2 * NN;                        // eigenvectors / temp
   double *X = V + NN;                            // MDS factor
   const int D = K + 1;
@@ -669,13 +675,13 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       const int u = e / N, bb = e - u * N;
       double best = -INFINITY;
       for (int q = 0; q < N; ++q) best = fmax(best, L[q * N + bb] - U[u * N + q]);
-      A[e] = best;
+      A1[e] = best;
     }
     __syncthreads();
     for (int e = tid; e < NN; e += PREP_NT) {  // V[u][v] = lb
       const int u = e / N, v = e - u * N;
       double best = 0.0;
-      for (int q = 0; q < N; ++q) best = fmax(best, A[u * N + q] - U[q * N + v]);
+      for (int q = 0; q < N; ++q) best = fmax(best, A1[u * N + q] - U[q * N + v]);
       V[e] = best;
     }
     __syncthreads();
