@@ -16,7 +16,7 @@ worst = 0.0
 for case in range(cases):
     N = int(rng.randint(6, 129))
     n_clique = int(rng.randint(4, N + 1))
-    P = rng.randn(N, 3) * rng.uniform(0.3, 2.0, 3)
+    P = rng.randn(N, 3) * rng.uniform(0.3, 2.0, 3) + rng.choice([0.0, 50.0]) * rng.randn(3)   # scenes far from the origin too
     Dtrue = ((P[:, None] - P[None]) ** 2).sum(-1)
     perm = rng.permutation(N)
     clique, other = perm[:n_clique], perm[n_clique:]
