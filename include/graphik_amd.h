@@ -72,7 +72,7 @@ typedef struct {
    * gik_template_create, as developer overrides of these fields)                             */
   int32_t waves_per_cu;      /* persistent solve waves (workgroups) per CU; 0 = automatic      */
   int32_t slice_outer_its;   /* time slice of the workgroup-per-problem kernel in outer
-                                iterations; -1 = default (256), 0 = no time slicing            */
+                                iterations; -1 = default (96), 0 = no time slicing             */
   int32_t debug_flags;       /* developer flags (gik_solve.hip: SolveArgs::dbg); 16 = rerun tCG
                                 after a rejected step instead of resuming from the checkpoint;
                                 workgroup path: 64 = closed form for rigid cliques from 4 nodes

@@ -405,7 +405,7 @@ def test_checkpoint_resume_is_bit_identical(torch_cuda, monkeypatch, name):
 @pytest.mark.parametrize("flags", [0, 64])     # 64: with the clique closed form (base + goal nodes)
 def test_time_slicing_is_bit_identical(torch_cuda, monkeypatch, flags):
     """The workgroup-per-problem kernel re-queues a problem that has not met a stopping rule after
-    slice_outer_its outer iterations (default 256) behind everything that is waiting, so that the long
+    slice_outer_its outer iterations (default 96) behind everything that is waiting, so that the long
     problems of a batch do not start last.  A solve is exactly resumable from (x, Delta,
     counters), so the results must not depend on the slice length; only the executed work may (the
     tCG checkpoint is dropped at a slice boundary)."""
