@@ -40,7 +40,7 @@ class Stats(C.Structure):
     """gik_stats (40 bytes per problem); engine.py sizes and decodes the stats buffer from this."""
     _fields_ = [("f", C.c_double), ("gradnorm", C.c_double), ("iterations", C.c_int32),
                 ("inner_total", C.c_int32), ("stop", C.c_int32), ("n_accept", C.c_int32),
-                ("inner_executed", C.c_int32), ("reserved", C.c_int32)]
+                ("inner_executed", C.c_int32), ("flags", C.c_int32)]
 
 
 STATS_BYTES = C.sizeof(Stats)

@@ -39,7 +39,8 @@ constexpr int BLOCK_NT = 512;
 constexpr int BLOCK_WAVES = BLOCK_NT / WAVE;
 constexpr int BLOCK_MAXN = BLOCK_NT / 4;  // 128 nodes
 constexpr int CLQ_M = BLOCK_MAXN / 4;     // clique partners per thread (row 4m + part, m < CLQ_M)
-constexpr int CLQ_NMOM = 18;              // Sw[3], M[3][3], T3[3], U3[3]
+constexpr int CLQ_NMOM = 30;              // Sw[3], M[3][3], T3[3], U3[3]; Euclidean targets: R3[3], P[3][3]
+constexpr int CLQ_NMOM0 = 18;             // ... of which the first 18 are always needed
 
 // launch-invariant tables of the workgroup-per-problem path (device pointers; gik_template_create)
 struct BlockTabs {
@@ -49,6 +50,7 @@ struct BlockTabs {
   const int *wave_sl;      // [8][2] slot-loop bounds {SLE, SL} of each wavefront
   int Tc;                  // terms kept in the slot tables
   int n_clq;               // clique size (rows 0..n_clq-1), 0 = none
+  int clq_euclid;          // 1: look for point coordinates behind the clique's target distances
 };
 
 template <int K>
@@ -72,6 +74,11 @@ struct BlockCtx {
   double Dr[CLQ_M];            // its squared target distance
   double rD, n_count;          // sum_j D_ij of the node; (double)n_clq
   double yt[3], ytp, y2t;      // centred row of the node, own entry, squared norm
+  // Euclidean targets: if the clique's D_ij are the squared distances of points X_j in R^3 (any
+  // rigid scene), D = r 1^T + 1 r^T - 2 X X^T has rank 5 and (D w)_i = r_i Sw + R3 - 2 P X_i with
+  // R3 = sum r_j w_j, P = sum w_j X_j^T: 12 more moments replace the O(n) product per node
+  bool lowrank;                // this problem's clique targets passed the check (block-uniform)
+  double Xr[3], rr;            // centred coordinates of the node, squared norm
   double *sh_mom;              // [CLQ_NMOM][BLOCK_WAVES] per-wave partial moments, then
                                // [8] Syy (xx xy xz yy yz zz), tr Syy, n of the committed point
   double *sh_Y;      // [128][4] accepted point
@@ -124,6 +131,9 @@ struct BlockCtx {
     wclq = __builtin_amdgcn_readfirstlane(wave * (WAVE / 4)) < n_clq;
     clq_valid = 0u;
     rD = 0.0;
+    lowrank = false;
+    rr = 0.0;
+    Xr[0] = Xr[1] = Xr[2] = 0.0;
     if constexpr (K == 3) {
 #pragma unroll
       for (int m = 0; m < CLQ_M; ++m) Dr[m] = 0.0;
@@ -151,9 +161,91 @@ struct BlockCtx {
         s += dpp_f64<0xB1>(s);
         s += dpp_f64<0x4E>(s);
         rD = s;
+        lowrank = false;
+        if (bt.clq_euclid && tg_b) {
+          __syncthreads();
+          lowrank = clique_coordinates(tg_b, bt);
+        }
       }
     }
     __syncthreads();
+  }
+
+  // block-wide argmax over the clique rows of a per-row value (held by every lane of the row);
+  // scratch: column `col` of sh_W.  Returns the row, the value in `best`.
+  __device__ inline int clique_argmax(double val, int col, double &best) {
+    if (part == 0) sh_W[node * RS + col] = (node < n_clq) ? val : -1.0;
+    __syncthreads();
+    double b = -1.0;
+    int arg = 0;
+    for (int j = 0; j < n_clq; ++j) {
+      const double v = sh_W[j * RS + col];
+      if (v > b) {
+        b = v;
+        arg = j;
+      }
+    }
+    __syncthreads();
+    best = b;
+    return arg;
+  }
+
+  // Are the clique's target distances those of a point set in R^3?  Coordinates by trilateration
+  // from four of its nodes -- row 0, the row farthest from it, the row farthest from their line, the
+  // row farthest from their plane -- then every pair is checked against its target at 1e-12 of
+  // the largest distance.  On success the centred coordinates of this thread's node are in Xr / rr
+  // and those of all rows in sh_P (x, y, z, |X|^2) until the solve overwrites them.
+  __device__ inline bool clique_coordinates(const double *tg_b, const BlockTabs &bt) {
+    const bool in = node < n_clq;
+    auto dist_to = [&](int a) -> double {   // D(node, a), a block-uniform
+      if (!in) return 0.0;
+      const int idx = bt.clq_term[(a >> 2) * BLOCK_NT + (node << 2) + (a & 3)];
+      return idx >= 0 ? tg_b[idx] : 0.0;
+    };
+    double m1, m2, m3;
+    const double d0 = dist_to(0);
+    const int a1 = clique_argmax(d0, 0, m1);
+    if (!(m1 > 0.0)) return false;
+    const double d01 = sqrt(m1);
+    const double x = (d0 + m1 - dist_to(a1)) / (2.0 * d01);
+    const int a2 = clique_argmax(d0 - x * x, 0, m2);
+    if (!(m2 > 1e-6 * m1)) return false;    // collinear
+    if (part == 0) sh_P[node * RS] = x;
+    __syncthreads();
+    const double x2 = sh_P[a2 * RS], y2 = sqrt(m2);
+    const double y = (d0 - dist_to(a2) + (x2 * x2 + m2) - 2.0 * x * x2) / (2.0 * y2);
+    const int a3 = clique_argmax(d0 - x * x - y * y, 0, m3);
+    if (!(m3 > 1e-6 * m1)) return false;    // coplanar
+    if (part == 0) sh_P[node * RS + 1] = y;
+    __syncthreads();
+    const double x3 = sh_P[a3 * RS], y3 = sh_P[a3 * RS + 1], z3 = sqrt(m3);
+    const double z = (d0 - dist_to(a3) + (x3 * x3 + y3 * y3 + m3) - 2.0 * x * x3 - 2.0 * y * y3) / (2.0 * z3);
+    const double lm = (in && part == 0) ? 1.0 : 0.0;
+    double c[3] = {lm * x, lm * y, lm * z};
+    sum_n<3>(c);
+    const double inv_n = 1.0 / n_count;
+    Xr[0] = fma(-c[0], inv_n, x);
+    Xr[1] = fma(-c[1], inv_n, y);
+    Xr[2] = fma(-c[2], inv_n, z);
+    rr = fma(Xr[2], Xr[2], fma(Xr[1], Xr[1], Xr[0] * Xr[0]));
+    if (in) sh_P[node * RS + part] = part == 0 ? Xr[0] : (part == 1 ? Xr[1] : (part == 2 ? Xr[2] : rr));
+    __syncthreads();
+    double bad = 0.0;
+    const double tol = 1e-12 * m1;
+    const double *pb = sh_P + part * RS;
+#pragma unroll
+    for (int m = 0; m < CLQ_M; ++m) {
+      if (m >= M_clq) continue;
+      double r[K];
+      row(pb, 4 * m, r);
+      const double e0 = Xr[0] - r[0], e1 = Xr[1] - r[1], e2 = Xr[2] - r[2];
+      const double e = fma(e2, e2, fma(e1, e1, e0 * e0)) - Dr[m];
+      bad += (((clq_valid >> m) & 1u) && !(fabs(e) <= tol)) ? 1.0 : 0.0;
+      if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    const double nbad = sum1(bad);
+    __syncthreads();   // sh_P is the solver's from here on
+    return nbad == 0.0;
   }
 
   template <int NV>
@@ -369,7 +461,7 @@ struct BlockCtx {
     if (!wclq) {
       if ((lane & 15) == 0 && lane < 48) {
 #pragma unroll
-        for (int r = 0; r < 6; ++r) sh_mom[(r * 3 + (lane >> 4)) * BLOCK_WAVES + wave] = 0.0;
+        for (int r = 0; r < 10; ++r) sh_mom[(r * 3 + (lane >> 4)) * BLOCK_WAVES + wave] = 0.0;
       }
       return;
     }
@@ -389,6 +481,20 @@ struct BlockCtx {
       const int i = lane >> 4;
 #pragma unroll
       for (int r = 0; r < 6; ++r) sh_mom[(r * 3 + i) * BLOCK_WAVES + wave] = v[r];
+    }
+    if (lowrank) {   // R3[p] = sum r_j w_j[p],  P[p][a] = sum w_j[p] X_j[a]  (index 21 + 3 a + p)
+      double u[4] = {rr * w, Xr[0] * w, Xr[1] * w, Xr[2] * w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(u[r], 1.0, 0.0, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u[r] += dpp_f64<0x128>(u[r]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u[r] += dpp_f64<0x124>(u[r]);
+      if ((lane & 15) == 0 && lane < 48) {
+        const int i = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sh_mom[((6 + r) * 3 + i) * BLOCK_WAVES + wave] = u[r];
+      }
     }
   }
 
@@ -434,9 +540,9 @@ struct BlockCtx {
     const double2 p01 = *reinterpret_cast<const double2 *>(p), p23 = *reinterpret_cast<const double2 *>(p + 2);
     const double2 p45 = *reinterpret_cast<const double2 *>(p + 4), p67 = *reinterpret_cast<const double2 *>(p + 6);
     const double tot = ((p01.x + p01.y) + (p23.x + p23.y)) + ((p45.x + p45.y) + (p67.x + p67.y));
-    double mo[CLQ_NMOM];
+    double mo[CLQ_NMOM0];
 #pragma unroll
-    for (int q = 0; q < CLQ_NMOM; ++q) mo[q] = readlane_f64(tot, q);
+    for (int q = 0; q < CLQ_NMOM0; ++q) mo[q] = readlane_f64(tot, q);
     // mo: Sw[c] = mo[c]; M[a][b] = mo[3 + 3a + b]; T3[c] = mo[12 + c]; U3[c] = mo[15 + c]
     const double s_yw = (mo[3] + mo[7]) + mo[11];
     const double a_i = fma(yt[2], wi[2], fma(yt[1], wi[1], yt[0] * wi[0]));
@@ -456,6 +562,14 @@ struct BlockCtx {
       const double G = fma(yt[q], g, My) + (Sw_ - mo[12 + q]);
       const double C = fma(wi[q], cw, -(y2t * mo[q])) + (fma(2.0, Mty, -mo[15 + q]));
       h[q] = fma(2.0, G, C);
+    }
+    if (lowrank) {   // + (D w)_i = r_i Sw + R3 - 2 P X_i
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const double PX = fma(readlane_f64(tot, 27 + q), Xr[2],
+                              fma(readlane_f64(tot, 24 + q), Xr[1], readlane_f64(tot, 21 + q) * Xr[0]));
+        h[q] += fma(rr, mo[q], readlane_f64(tot, 18 + q)) - (PX + PX);
+      }
     }
     const double hs = part == 0 ? h[0] : (part == 1 ? h[1] : h[2]);
     return (node < n_clq && part < 3) ? hs : 0.0;
@@ -491,7 +605,7 @@ struct BlockCtx {
 #ifdef GIK_BLK_PROF
         pt1a = __builtin_readcyclecounter();
 #endif
-        clique_dw(acc);
+        if (!lowrank) clique_dw(acc);
 #ifdef GIK_BLK_PROF
         pt1b = __builtin_readcyclecounter();
 #endif

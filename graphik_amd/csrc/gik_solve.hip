@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
       s.stop = stop;
       s.n_accept = n_accept;
       s.inner_executed = ro.inner_executed;
-      s.reserved = 0;
+      s.flags = 0;
       a.stats[b] = s;
     }
   }
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(WAVE, 2) rcg_wave_kernel(SolveArgs a) {
       s.stop = ro.stop;
       s.n_accept = ro.n_accept;
       s.inner_executed = ro.inner_executed;
-      s.reserved = 0;
+      s.flags = 0;
       a.stats[b] = s;
     }
   }
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
       s.stop = ro.stop;
       s.n_accept = ro.n_accept;
       s.inner_executed = ro.inner_executed;
-      s.reserved = 0;
+      s.flags = cx.lowrank ? 1 : 0;
       a.stats[b] = s;
       if (a.slice_its > 0) __hip_atomic_fetch_add(a.q_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(BLOCK_NT) rcg_block_kernel(SolveArgs a, int SL
       s.stop = ro.stop;
       s.n_accept = ro.n_accept;
       s.inner_executed = ro.inner_executed;
-      s.reserved = 0;
+      s.flags = cx.lowrank ? 1 : 0;
       a.stats[b] = s;
     }
   }
@@ -755,7 +755,7 @@ struct gik_template {
   bool is_block;  // workgroup-per-problem path
   int SL;         // slots per thread on the block path
   int SLE;        // ... of which the first SLE hold equality terms (or padding) only
-  gik::BlockTabs bt = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+  gik::BlockTabs bt = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
   // device pre/post-processing (gik_pipeline_attach)
   bool has_pipe;
   gik::PipeConst pc;
@@ -1163,6 +1163,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     t->bt.wave_sl = upload(t, wave_sl.data(), wave_sl.size(), ok);
     t->bt.Tc = Tc;
     t->bt.n_clq = n_clq;
+    t->bt.clq_euclid = (n_clq && !(dbg_eff & 256)) ? 1 : 0;   // 256: always the dense D w product
     if (!ok) {
       gik_template_destroy(t);
       return fail("device upload of the workgroup-path tables failed");

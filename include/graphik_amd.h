@@ -107,7 +107,9 @@ typedef struct {
                           reference's next tCG solve repeats the previous one up to the smaller
                           radius, and the engine resumes from a checkpoint instead (same result,
                           bit for bit); inner_total counts what the reference would have run   */
-  int32_t reserved;
+  int32_t flags;       /* bit 0: workgroup kernels, rigid clique: the clique's target distances were
+                          those of a point set in R^3 and its dense D w product was replaced by
+                          moments (informational; results agree to round-off either way)   */
 } gik_stats;            /* 40 bytes                                                         */
 
 /* Optional per-outer-iteration trace (device arrays of B x cap; pass NULL to disable). */

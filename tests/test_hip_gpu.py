@@ -753,8 +753,9 @@ def test_device_pipeline_end_to_end(torch_cuda, name, B):
 
 # ---- workgroup-per-problem path (graphs with N*k > 64) -------------------------------------------
 # debug_flags of the workgroup-per-problem path: 64 = closed form for rigid cliques from 4 nodes up
-# (default 16: the small robots' base + goal nodes then exercise it), 128 = closed form off
-@pytest.mark.parametrize("name,flags", [("ur10_table", 0), ("ur10_table", 128), ("lwa4d", 0), ("lwa4d", 64),
+# (default 16: the small robots' base + goal nodes then exercise it), 128 = closed form off,
+# 256 = closed form with the dense D w product even when the targets are distances of points
+@pytest.mark.parametrize("name,flags", [("ur10_table", 0), ("ur10_table", 256), ("ur10_table", 128), ("lwa4d", 0), ("lwa4d", 64),
                                         ("kuka", 64), ("planar10_limits_halfpi", 0)])
 def test_block_path_known_answers(torch_cuda, name, flags):
     """UR10 + table_environment(): 116 nodes, 5612 residual terms (BASELINE configs[2]) runs on
@@ -822,19 +823,26 @@ def test_clique_closed_form_against_direct_sum(torch_cuda):
         assert np.abs(Tc.hess(Y, W, tg).cpu().numpy() - hd).max() < 1e-12 * np.abs(hd).max()
     fd, fc = rd["f"].cpu().numpy(), rc["f"].cpu().numpy()
     assert np.array_equal(fd < 1e-9, fc < 1e-9)
+    # the scene's targets are distances of points: the closed form runs without the dense product
+    assert np.all(rc["flags"].cpu().numpy() == 1) and np.all(rd["flags"].cpu().numpy() == 0)
     itd, itc = rd["iterations"].cpu().numpy().astype(float), rc["iterations"].cpu().numpy().astype(float)
     assert np.all(np.abs(itc / itd - 1.0) < 0.25), (itd, itc)
     hvd, hvc = float(rd["inner_total"].sum()), float(rc["inner_total"].sum())
     assert abs(hvc / hvd - 1.0) < 0.15, (hvd, hvc)
 
 
-@pytest.mark.parametrize("n_clique,n_other", [(21, 19), (16, 3), (45, 0), (106, 10)])
-def test_clique_detection_on_synthetic_graphs(torch_cuda, n_clique, n_other):
+@pytest.mark.parametrize("n_clique,n_other,euclid", [(21, 19, True), (16, 3, True), (45, 0, True), (106, 10, True),
+                                                    (21, 19, False), (64, 8, False), (40, 5, "planar")])
+def test_clique_detection_on_synthetic_graphs(torch_cuda, n_clique, n_other, euclid):
     """Synthetic 3-D graphs on the workgroup path: a rigid clique whose size is not a multiple of
     four, with lower / upper hinges ON TOP of some clique pairs (they stay in the slot tables), other
     nodes chained to the clique and to each other, the clique's nodes scattered over the node
     numbering -- cost, gradient and Hessian product against the CPU oracle at 1e-12, closed form and
-    direct sum, and one solve ending at the same cost."""
+    direct sum, and one solve ending at the same cost.  With Euclidean targets (the squared distances
+    of a point set, as every scene gives) the kernel finds coordinates for the clique and replaces
+    its dense D w product by 12 more moments; targets that are NOT distances of points in space (each
+    scaled by its own factor), or whose points lie in a plane (no frame for the trilateration), must
+    take the dense product and give the same answers."""
     from oracle import c_oracle as co
     from graphik_amd.engine import Template
     rng = np.random.RandomState(11 + n_clique)
@@ -860,12 +868,18 @@ def test_clique_detection_on_synthetic_graphs(torch_cuda, n_clique, n_other):
                 pU[i, j] = pU[j, i] = 1.5 * Dtrue[i, j]
     il = co.limit_inds(om, pL, pU)
     D = Dtrue * om
+    if euclid == "planar":
+        P[clique, 2] = 0.25          # the clique's points in one plane (other nodes off it)
+        D = ((P[:, None] - P[None]) ** 2).sum(-1) * om
+    elif not euclid:
+        S = 1.0 + 0.1 * rng.rand(N, N)
+        D = D * (S + S.T)
     Y = P + 0.3 * rng.randn(N, 3)
     W = rng.randn(N, 3)
     want = (co.lcost(Y, D, om, pL, pU, il), co.lgrad(Y, D, om, pL, pU, il), co.lhess(Y, W, D, om, pL, pU, il))
     fs = []
     # (the largest case only fits the LDS with the clique taken out of the slot tables)
-    for flags in ((0, 128) if n_clique < 64 else (0,)):
+    for flags in ((0, 256, 128) if n_clique < 64 else (0, 256)):
         T = Template.from_matrices(om, pL, pU, k=3, use_limits=True,
                                    params={"force_block_path": 1, "debug_flags": flags})
         tg = T.targets_from_D(D)
@@ -874,7 +888,12 @@ def test_clique_detection_on_synthetic_graphs(torch_cuda, n_clique, n_other):
         assert rel_err(T.hess(Y, W, tg)[0].cpu().numpy(), want[2]) < 1e-12
         r = T.solve(Y[None], tg[None] if tg.ndim == 1 else tg)
         fs.append(float(r["f"][0]))
-    assert max(fs) < 1e-9
+        # which rendering of the clique's D w product ran (gik_stats.flags bit 0)
+        assert int(r["flags"][0]) == (1 if (euclid is True and flags == 0) else 0)
+    if euclid is True:
+        assert max(fs) < 1e-9
+    else:                       # inconsistent targets / hinges: a positive minimum, the same for both renderings
+        assert max(fs) > 1e-6 and abs(fs[0] - fs[-1]) < 1e-6 * fs[0]
 
 
 def test_busy_nodes_fall_back_to_block_path(torch_cuda):

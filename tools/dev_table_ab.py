@@ -7,7 +7,7 @@ from graphik_amd.engine import Template
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 d = np.load("tests/golden/ur10_table.npz")
 out = {}
-for flags in (128, 0):
+for flags in (128, 256, 0):
     T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=3, use_limits=True,
                                params={"debug_flags": flags})
     G = len(d["Y_init"])
@@ -15,8 +15,8 @@ for flags in (128, 0):
     r = T.solve(Yi, tg); torch.cuda.synchronize()
     t0 = time.time(); r = T.solve(Yi, tg); torch.cuda.synchronize(); dt = time.time() - t0
     ex = r["inner_executed"].cpu().numpy().astype(float)
-    print("clique %s B=%d: %.3f s, executed products %.3g total, max %d -> %.2f us per product per CU-resident problem; %.1f solves/s"
-          % ("off" if flags else "on ", len(Yi), dt, ex.sum(), ex.max(), dt * min(len(Yi), 256) / ex.sum() * 1e6, len(Yi) / dt), flush=True)
+    print("flags %s B=%d: %.3f s, executed products %.3g total, max %d -> %.2f us per product per CU-resident problem; %.1f solves/s"
+          % (str(flags).rjust(3), len(Yi), dt, ex.sum(), ex.max(), dt * min(len(Yi), 256) / ex.sum() * 1e6, len(Yi) / dt), flush=True)
     out[flags] = {k: r[k].cpu().numpy() for k in ("x", "f", "iterations", "inner_total", "stop")}
 a, b = out[128], out[0]
 print("iterations off/on:", a["iterations"][:G], b["iterations"][:G])
