@@ -1174,6 +1174,11 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
               "clique %d, slot terms %d, slots %d\n",
               t->N, t->K, t->T, is_block ? "block" : "wave", is_block ? 0 : t->variant->maxdeg,
               t->smem_bytes, occ, t->n_cu, n_clq, Tc, SL);
+  if ((t->dbg & 32) && is_block) {
+    fprintf(stderr, "  slot loop bounds per wavefront {equalities, all}:");
+    for (int w = 0; w < BLOCK_WAVES; ++w) fprintf(stderr, " {%d, %d}", wave_sl[2 * w], wave_sl[2 * w + 1]);
+    fprintf(stderr, "\n");
+  }
   *out = t;
   return 0;
 }
