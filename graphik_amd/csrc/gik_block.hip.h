@@ -40,7 +40,6 @@ constexpr int BLOCK_WAVES = BLOCK_NT / WAVE;
 constexpr int BLOCK_MAXN = BLOCK_NT / 4;  // 128 nodes
 constexpr int CLQ_M = BLOCK_MAXN / 4;     // clique partners per thread (row 4m + part, m < CLQ_M)
 constexpr int CLQ_NMOM = 30;              // Sw[3], M[3][3], T3[3], U3[3]; Euclidean targets: R3[3], P[3][3]
-constexpr int CLQ_NMOM0 = 18;             // ... of which the first 18 are always needed
 
 // launch-invariant tables of the workgroup-per-problem path (device pointers; gik_template_create)
 struct BlockTabs {
@@ -95,7 +94,7 @@ struct BlockCtx {
 
   __host__ __device__ static constexpr size_t lds_bytes(int T, int SL) {
     return sizeof(double) * ((size_t)3 * BLOCK_MAXN * RS + (size_t)((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES +
-                             CLQ_NMOM * BLOCK_WAVES + 8) +
+                             CLQ_NMOM * BLOCK_WAVES + 8 + 32 * BLOCK_WAVES) +
            sizeof(uint32_t) * (size_t)SL * BLOCK_NT + (HAS_CK ? sizeof(double) * 4 * BLOCK_NT : 0);
   }
 
@@ -533,42 +532,66 @@ struct BlockCtx {
   }
 
   // the O(1)-per-node part of the clique's Hessian-vector product (see the file header), entry
-  // `part` of node `node`; call after the barrier that publishes sh_W and sh_mom
+  // `part` of node `node`; call after the barrier that publishes sh_W and sh_mom.
+  // Lanes 0..29 add the eight partials of one moment each; the totals go through a 32-double LDS
+  // strip of the wave's own and come back as broadcast reads (every lane the same address), each
+  // used where it is read: 16 LDS instructions instead of 60 v_readlane into scalar registers.
   __device__ inline double clique_closed_form(const double (&wi)[K]) {
     static_assert(BLOCK_WAVES == 8, "eight partials per moment");
     const double *p = sh_mom + (lane < CLQ_NMOM ? lane : 0) * BLOCK_WAVES;
     const double2 p01 = *reinterpret_cast<const double2 *>(p), p23 = *reinterpret_cast<const double2 *>(p + 2);
     const double2 p45 = *reinterpret_cast<const double2 *>(p + 4), p67 = *reinterpret_cast<const double2 *>(p + 6);
     const double tot = ((p01.x + p01.y) + (p23.x + p23.y)) + ((p45.x + p45.y) + (p67.x + p67.y));
-    double mo[CLQ_NMOM0];
-#pragma unroll
-    for (int q = 0; q < CLQ_NMOM0; ++q) mo[q] = readlane_f64(tot, q);
-    // mo: Sw[c] = mo[c]; M[a][b] = mo[3 + 3a + b]; T3[c] = mo[12 + c]; U3[c] = mo[15 + c]
-    const double s_yw = (mo[3] + mo[7]) + mo[11];
-    const double a_i = fma(yt[2], wi[2], fma(yt[1], wi[1], yt[0] * wi[0]));
-    const double ySw = fma(yt[2], mo[2], fma(yt[1], mo[1], yt[0] * mo[0]));
+    double *strip = sh_mom + CLQ_NMOM * BLOCK_WAVES + 8 + 32 * wave;
+    if (lane < 32) strip[lane] = tot;
+    __builtin_amdgcn_wave_barrier();
     const double *cq = sh_mom + CLQ_NMOM * BLOCK_WAVES;
     const double2 c01 = *reinterpret_cast<const double2 *>(cq), c23 = *reinterpret_cast<const double2 *>(cq + 2);
     const double2 c45 = *reinterpret_cast<const double2 *>(cq + 4), c67 = *reinterpret_cast<const double2 *>(cq + 6);
-    const double g = fma(c67.y, a_i, s_yw) - ySw;
+    const double a_i = fma(yt[2], wi[2], fma(yt[1], wi[1], yt[0] * wi[0]));
     const double cw = fma(c67.y, y2t, c67.x) - rD;
+    const double ty[3] = {yt[0] + yt[0], yt[1] + yt[1], yt[2] + yt[2]};
     const double S[3][3] = {{c01.x, c01.y, c23.x}, {c01.y, c23.y, c45.x}, {c23.x, c45.x, c45.y}};
     double h[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const double My = fma(mo[3 + 3 * q + 2], yt[2], fma(mo[3 + 3 * q + 1], yt[1], mo[3 + 3 * q] * yt[0]));
-      const double Mty = fma(mo[9 + q], yt[2], fma(mo[6 + q], yt[1], mo[3 + q] * yt[0]));
+    for (int q = 0; q < 3; ++q) {   // w_q cw + 2 (Syy w)_q
       const double Sw_ = fma(S[q][2], wi[2], fma(S[q][1], wi[1], S[q][0] * wi[0]));
-      const double G = fma(yt[q], g, My) + (Sw_ - mo[12 + q]);
-      const double C = fma(wi[q], cw, -(y2t * mo[q])) + (fma(2.0, Mty, -mo[15 + q]));
-      h[q] = fma(2.0, G, C);
+      h[q] = fma(wi[q], cw, Sw_ + Sw_);
     }
-    if (lowrank) {   // + (D w)_i = r_i Sw + R3 - 2 P X_i
+    auto mom = [&](int k) -> double { return strip[k]; };   // adjacent k share a 16-byte read
+    // Sw: - |y~|^2 Sw (+ r Sw with Euclidean targets), and y~ . Sw for g
+    const double dy = lowrank ? rr - y2t : -y2t;
+    double ySw = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double v = mom(q);
+      ySw = fma(yt[q], v, ySw);
+      h[q] = fma(dy, v, h[q]);
+    }
+    // M[a][b]: 2 (M y~)_a + 2 (M^T y~)_b, trace for g
+    double s_yw = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const double v = mom(3 + 3 * a + b);
+        h[a] = fma(ty[b], v, h[a]);
+        h[b] = fma(ty[a], v, h[b]);
+        if (a == b) s_yw += v;
+      }
+    // - 2 T3 - U3
+#pragma unroll
+    for (int q = 0; q < 3; ++q) h[q] = fma(-2.0, mom(12 + q), h[q]) - mom(15 + q);
+    const double g = fma(c67.y, a_i, s_yw) - ySw;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) h[q] = fma(ty[q], g, h[q]);
+    if (lowrank) {   // + (D w)_i = r_i Sw + R3 - 2 P X_i   (r_i Sw is in dy above)
+      const double nx[3] = {-(Xr[0] + Xr[0]), -(Xr[1] + Xr[1]), -(Xr[2] + Xr[2])};
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        const double PX = fma(readlane_f64(tot, 27 + q), Xr[2],
-                              fma(readlane_f64(tot, 24 + q), Xr[1], readlane_f64(tot, 21 + q) * Xr[0]));
-        h[q] += fma(rr, mo[q], readlane_f64(tot, 18 + q)) - (PX + PX);
+        h[q] += mom(18 + q);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) h[q] = fma(nx[a], mom(21 + 3 * a + q), h[q]);
       }
     }
     const double hs = part == 0 ? h[0] : (part == 1 ? h[1] : h[2]);
