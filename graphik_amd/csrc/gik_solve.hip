@@ -981,19 +981,23 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
           clq_term[(size_t)m * BLOCK_NT + tid] = eqterm[(size_t)node_of_row[row] * N + node_of_row[j]];
       }
     }
-    // four threads per node, a contiguous quarter of the node's terms each; within a thread the
-    // equality terms come first (slots [0, SLE_w): no kind decoding in the kernels) and the hinge
-    // terms last (slots [SLE_w, SL_w)), with the bounds of the thread's wavefront w; unused
-    // slots are inert padding (own node, kind 0, not owner)
+    // four threads per node; a node's equality terms are dealt to them in turn, then its hinge
+    // terms continuing the rotation, so that both kinds spread evenly (the padded slot count of a
+    // wavefront is the largest equality count plus the largest hinge count among its threads:
+    // 3 + 2 -> 2 + 1 for the free nodes of the table scene).  Within a thread the equality terms
+    // come first (slots [0, SLE_w): no kind decoding in the kernels) and the hinge terms last
+    // (slots [SLE_w, SL_w)), with the bounds of the thread's wavefront w; unused slots are inert
+    // padding (own node, kind 0, not owner)
     std::vector<std::vector<Ent>> eqs(BLOCK_NT), hinges(BLOCK_NT);
+    for (int node = 0; node < BLOCK_MAXN; ++node) {
+      int turn = 0;
+      for (int pass = 0; pass < 2; ++pass)
+        for (const Ent &en : ents[node])
+          if ((en.kind == GIK_TERM_EQ) == (pass == 0))
+            (pass == 0 ? eqs : hinges)[4 * node + (turn++ & 3)].push_back(en);
+    }
     for (int tid = 0; tid < BLOCK_NT; ++tid) {
-      const int node = tid >> 2, part = tid & 3, w = tid / WAVE;
-      const int dg = (int)ents[node].size();
-      const int L = (dg + 3) / 4;
-      for (int e = part * L; e < std::min(dg, (part + 1) * L); ++e) {
-        const Ent &en = ents[node][e];
-        (en.kind == GIK_TERM_EQ ? eqs : hinges)[tid].push_back(en);
-      }
+      const int w = tid / WAVE;
       wave_sl[2 * w] = std::max(wave_sl[2 * w], (int)eqs[tid].size());
       wave_sl[2 * w + 1] = std::max(wave_sl[2 * w + 1], (int)hinges[tid].size());
     }
