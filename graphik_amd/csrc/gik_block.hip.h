@@ -498,37 +498,24 @@ struct BlockCtx {
   }
 
   __device__ inline void clique_dw(double (&acc)[K]) {
-    // (D w)_i: partner rows 4m + part, a quarter of the clique per thread, in groups of four
-    // (Dr = 0 beyond the clique and rows up to 127 exist, so whole groups are run: one scalar
-    // branch per group).  The rows of group g + 1 are requested before the FMAs of group g,
-    // and two accumulator sets halve the dependent chains.
+    // (D w)_i, dense: partner rows 4m + part, a quarter of the clique per thread, in groups of four
+    // (D = 0 beyond the clique and rows up to 127 exist, so whole groups are run: one scalar
+    // branch per group).  Only for targets that are not distances of points (clique_coordinates),
+    // so it is kept small: its registers add to the budget of the loop every problem runs.
     const double *wb = sh_W + part * RS;
-    double buf[2][4][K], acc1[K];
-#pragma unroll
-    for (int q = 0; q < K; ++q) acc1[q] = 0.0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) row(wb, 4 * u, buf[0][u]);
 #pragma unroll
     for (int g = 0; g < CLQ_M / 4; ++g) {
       if (4 * g >= M_clq) continue;
-      if (g + 1 < CLQ_M / 4 && 4 * (g + 1) < M_clq) {
+      double buf[4][K];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) row(wb, 4 * (4 * (g + 1) + u), buf[(g + 1) & 1][u]);
-      }
+      for (int u = 0; u < 4; ++u) row(wb, 4 * (4 * g + u), buf[u]);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
 #pragma unroll
-        for (int q = 0; q < K; ++q) {
-          if (u & 1)
-            acc1[q] = fma(Dr[4 * g + u], buf[g & 1][u][q], acc1[q]);
-          else
-            acc[q] = fma(Dr[4 * g + u], buf[g & 1][u][q], acc[q]);
-        }
+        for (int q = 0; q < K; ++q) acc[q] = fma(Dr[4 * g + u], buf[u][q], acc[q]);
       }
       __builtin_amdgcn_sched_barrier(0);   // do not hoist later groups' loads (registers)
     }
-#pragma unroll
-    for (int q = 0; q < K; ++q) acc[q] += acc1[q];
   }
 
   // the O(1)-per-node part of the clique's Hessian-vector product (see the file header), entry
