@@ -39,6 +39,7 @@ constexpr int BLOCK_NT = 512;
 constexpr int BLOCK_WAVES = BLOCK_NT / WAVE;
 constexpr int BLOCK_MAXN = BLOCK_NT / 4;  // 128 nodes
 constexpr int CLQ_M = BLOCK_MAXN / 4;     // clique partners per thread (row 4m + part, m < CLQ_M)
+constexpr int CLQ_NCQ = 12;               // per accepted point: Syy (3 x 3, row-major), tr Syy, n, pad
 constexpr int CLQ_NMOM = 30;              // Sw[3], M[3][3], T3[3], U3[3]; Euclidean targets: R3[3], P[3][3]
 
 // launch-invariant tables of the workgroup-per-problem path (device pointers; gik_template_create)
@@ -94,7 +95,7 @@ struct BlockCtx {
 
   __host__ __device__ static constexpr size_t lds_bytes(int T, int SL) {
     return sizeof(double) * ((size_t)3 * BLOCK_MAXN * RS + (size_t)((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES +
-                             CLQ_NMOM * BLOCK_WAVES + 8 + 32 * BLOCK_WAVES) +
+                             CLQ_NMOM * BLOCK_WAVES + CLQ_NCQ + 32 * BLOCK_WAVES) +
            sizeof(uint32_t) * (size_t)SL * BLOCK_NT + (HAS_CK ? sizeof(double) * 4 * BLOCK_NT : 0);
   }
 
@@ -444,10 +445,12 @@ struct BlockCtx {
     sum_n<6>(x);
     if (tid == 0) {   // uniform; read back (broadcast) by clique_closed_form after the next barrier
       double *cq = sh_mom + CLQ_NMOM * BLOCK_WAVES;
-#pragma unroll
-      for (int q = 0; q < 6; ++q) cq[q] = x[q];
-      cq[6] = (x[0] + x[3]) + x[5];
-      cq[7] = n_count;
+      cq[0] = x[0]; cq[1] = x[1]; cq[2] = x[2];
+      cq[3] = x[1]; cq[4] = x[3]; cq[5] = x[4];
+      cq[6] = x[2]; cq[7] = x[4]; cq[8] = x[5];
+      cq[9] = (x[0] + x[3]) + x[5];
+      cq[10] = n_count;
+      cq[11] = 0.0;
     }
   }
 
@@ -521,68 +524,45 @@ struct BlockCtx {
   // the O(1)-per-node part of the clique's Hessian-vector product (see the file header), entry
   // `part` of node `node`; call after the barrier that publishes sh_W and sh_mom.
   // Lanes 0..29 add the eight partials of one moment each; the totals go through a 32-double LDS
-  // strip of the wave's own and come back as broadcast reads (every lane the same address), each
-  // used where it is read: 16 LDS instructions instead of 60 v_readlane into scalar registers.
+  // strip of the wave's own and come back as LDS reads instead of 60 v_readlane into scalar
+  // registers.
   __device__ inline double clique_closed_form(const double (&wi)[K]) {
     static_assert(BLOCK_WAVES == 8, "eight partials per moment");
     const double *p = sh_mom + (lane < CLQ_NMOM ? lane : 0) * BLOCK_WAVES;
     const double2 p01 = *reinterpret_cast<const double2 *>(p), p23 = *reinterpret_cast<const double2 *>(p + 2);
     const double2 p45 = *reinterpret_cast<const double2 *>(p + 4), p67 = *reinterpret_cast<const double2 *>(p + 6);
     const double tot = ((p01.x + p01.y) + (p23.x + p23.y)) + ((p45.x + p45.y) + (p67.x + p67.y));
-    double *strip = sh_mom + CLQ_NMOM * BLOCK_WAVES + 8 + 32 * wave;
+    double *strip = sh_mom + CLQ_NMOM * BLOCK_WAVES + CLQ_NCQ + 32 * wave;
     if (lane < 32) strip[lane] = tot;
     __builtin_amdgcn_wave_barrier();
+    // Each lane evaluates ITS component q = part: the moments it needs are picked by address
+    // (Sw_q, row q and column q of M, T3_q, U3_q, R3_q, column q of P^T), the ones every lane needs
+    // (Sw for y~ . Sw, the diagonal of M) are broadcast reads.
+    const int q = part < 3 ? part : 0;
     const double *cq = sh_mom + CLQ_NMOM * BLOCK_WAVES;
-    const double2 c01 = *reinterpret_cast<const double2 *>(cq), c23 = *reinterpret_cast<const double2 *>(cq + 2);
-    const double2 c45 = *reinterpret_cast<const double2 *>(cq + 4), c67 = *reinterpret_cast<const double2 *>(cq + 6);
-    const double a_i = fma(yt[2], wi[2], fma(yt[1], wi[1], yt[0] * wi[0]));
-    const double cw = fma(c67.y, y2t, c67.x) - rD;
+    const double *sq = strip + q;
+    const double Sq0 = cq[3 * q], Sq1 = cq[3 * q + 1], Sq2 = cq[3 * q + 2];
+    const double s_yy = cq[9], nn = cq[10];
+    const double wq = part == 0 ? wi[0] : (part == 1 ? wi[1] : wi[2]);
     const double ty[3] = {yt[0] + yt[0], yt[1] + yt[1], yt[2] + yt[2]};
-    const double S[3][3] = {{c01.x, c01.y, c23.x}, {c01.y, c23.y, c45.x}, {c23.x, c45.x, c45.y}};
-    double h[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {   // w_q cw + 2 (Syy w)_q
-      const double Sw_ = fma(S[q][2], wi[2], fma(S[q][1], wi[1], S[q][0] * wi[0]));
-      h[q] = fma(wi[q], cw, Sw_ + Sw_);
+    const double a_i = fma(yt[2], wi[2], fma(yt[1], wi[1], yt[0] * wi[0]));
+    const double ySw = fma(yt[2], strip[2], fma(yt[1], strip[1], yt[0] * strip[0]));
+    const double s_yw = (strip[3] + strip[7]) + strip[11];
+    const double g = fma(nn, a_i, s_yw) - ySw;
+    const double cw = fma(nn, y2t, s_yy) - rD;
+    const double Syw = fma(Sq2, wi[2], fma(Sq1, wi[1], Sq0 * wi[0]));
+    double h = fma(wq, cw, Syw + Syw);                                        // w_q cw + 2 (Syy w)_q
+    h = fma(lowrank ? rr - y2t : -y2t, sq[0], h);                             // (r_i - |y~|^2) Sw_q
+    const double *mr = strip + 3 + 3 * q;                                     // row q of M: 2 (M y~)_q
+    h = fma(ty[2], mr[2], fma(ty[1], mr[1], fma(ty[0], mr[0], h)));
+    h = fma(ty[2], sq[9], fma(ty[1], sq[6], fma(ty[0], sq[3], h)));           // column q: 2 (M^T y~)_q
+    h = fma(-2.0, sq[12], h) - sq[15];                                        // - 2 T3_q - U3_q
+    h = fma(ytp + ytp, g, h);                                                 // 2 y~_q g
+    if (lowrank) {   // + R3_q - 2 (P X_i)_q,  P[q][a] at 21 + 3 a + q
+      h += sq[18];
+      h = fma(-(Xr[2] + Xr[2]), sq[27], fma(-(Xr[1] + Xr[1]), sq[24], fma(-(Xr[0] + Xr[0]), sq[21], h)));
     }
-    auto mom = [&](int k) -> double { return strip[k]; };   // adjacent k share a 16-byte read
-    // Sw: - |y~|^2 Sw (+ r Sw with Euclidean targets), and y~ . Sw for g
-    const double dy = lowrank ? rr - y2t : -y2t;
-    double ySw = 0.0;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const double v = mom(q);
-      ySw = fma(yt[q], v, ySw);
-      h[q] = fma(dy, v, h[q]);
-    }
-    // M[a][b]: 2 (M y~)_a + 2 (M^T y~)_b, trace for g
-    double s_yw = 0.0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        const double v = mom(3 + 3 * a + b);
-        h[a] = fma(ty[b], v, h[a]);
-        h[b] = fma(ty[a], v, h[b]);
-        if (a == b) s_yw += v;
-      }
-    // - 2 T3 - U3
-#pragma unroll
-    for (int q = 0; q < 3; ++q) h[q] = fma(-2.0, mom(12 + q), h[q]) - mom(15 + q);
-    const double g = fma(c67.y, a_i, s_yw) - ySw;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) h[q] = fma(ty[q], g, h[q]);
-    if (lowrank) {   // + (D w)_i = r_i Sw + R3 - 2 P X_i   (r_i Sw is in dy above)
-      const double nx[3] = {-(Xr[0] + Xr[0]), -(Xr[1] + Xr[1]), -(Xr[2] + Xr[2])};
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        h[q] += mom(18 + q);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) h[q] = fma(nx[a], mom(21 + 3 * a + q), h[q]);
-      }
-    }
-    const double hs = part == 0 ? h[0] : (part == 1 ? h[1] : h[2]);
-    return (node < n_clq && part < 3) ? hs : 0.0;
+    return (node < n_clq && part < 3) ? h : 0.0;
   }
 
   // ehess(Y, W) (lhess / jhess, costs.py:175-207, 39-58) at the committed point sh_Y

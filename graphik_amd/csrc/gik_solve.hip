@@ -341,7 +341,7 @@ __device__ inline uint32_t *block_stage(BlockCtx<K> &cx, double *smem, const uin
   for (int t = tid; t < 3 * BLOCK_MAXN * BlockCtx<K>::RS; t += BLOCK_NT) smem[t] = 0.0;
   double *tg = smem + 3 * BLOCK_MAXN * BlockCtx<K>::RS;
   uint32_t *slots =
-      reinterpret_cast<uint32_t *>(tg + ((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES + CLQ_NMOM * BLOCK_WAVES + 8 +
+      reinterpret_cast<uint32_t *>(tg + ((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES + CLQ_NMOM * BLOCK_WAVES + CLQ_NCQ +
                                    32 * BLOCK_WAVES);
   for (int s = 0; s < SL; ++s) slots[s * BLOCK_NT + tid] = g_slots[s * BLOCK_NT + tid];
   cx.init(N, SL, bt, smem, slots, T);
