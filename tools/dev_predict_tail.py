@@ -24,7 +24,7 @@ work = full["inner_executed"].cpu().numpy().astype(float) + 8.0 * full["iteratio
 its = full["iterations"].cpu().numpy()
 maxit = its >= 3000
 print(f"{name} B={B}: maxiter {maxit.mean():.4f}, total work {work.sum():.3g}, max {work.max():.3g}, mean {work.mean():.3g}")
-S = 1024   # SIMDs
+S = int(os.environ.get("SIM_SERVERS", "1024"))   # SIMDs (wavefront kernel) or CUs (workgroup kernel)
 cyc = 972 / 2.4e6   # ms per product-unit
 
 def fast_sim(order, w, slots=2, slow=1.35):
