@@ -415,7 +415,12 @@ def main():
                              "the solve is LDS/register resident and bound by the instruction issue "
                              "rate of one wavefront per problem (and, at this batch size, by the "
                              "slowest problem), not by HBM or MFMA (SURVEY 8(d), DESIGN 4.1); "
-                             "peak = MI355X fp64 vector/matrix spec"},
+                             "peak = MI355X fp64 vector/matrix spec"
+                             + ("" if N * k <= 64 else
+                                "; workgroup-per-problem kernel: `achieved` is the ALGORITHMIC flop count "
+                                "of SURVEY 8(d) (12 k |E| per product) -- a rigid anchor clique is "
+                                "evaluated in closed form with about a tenth of those operations "
+                                "(DESIGN 4.1)")},
         "roofline_hbm": {"bound": "hbm", "achieved": hbm_bytes / (kernel_ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -424,13 +429,16 @@ def main():
     if serving is not None:
         out["serving"] = serving
     traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json")
-    if os.path.exists(traffic_file) and robot_name == "lwa4d" and B == 4096:   # profiled workload only
+    if robot_name == "ur10_table" and not args.intended:
+        traffic_file = os.path.join(REPO, "profiles", "r02_block_hbm_traffic.json")
+    if os.path.exists(traffic_file) and ((robot_name == "lwa4d" and B == 4096) or
+                                         (robot_name == "ur10_table" and B == 4096 and not args.intended)):   # profiled workloads only
         try:
             tj = json.load(open(traffic_file))
             out["roofline"]["traffic"] = tj.get("bytes_per_launch")
-            out["roofline"]["traffic_source"] = ("profiles/hbm_traffic.json: rocprofv3 --pmc passes of "
-                                                 "this command in a separate run (" +
-                                                 "tools/profile.sh r02 + tools/summarize_prof.py" + "), not "
+            out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(traffic_file)}: rocprofv3 --pmc "
+                                                 "passes of this command in a separate run "
+                                                 "(tools/profile.sh + tools/summarize_prof.py), not "
                                                  "measured by the process that printed this line")
         except Exception:
             pass
