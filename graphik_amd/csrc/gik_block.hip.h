@@ -40,7 +40,7 @@ constexpr int BLOCK_WAVES = BLOCK_NT / WAVE;
 constexpr int BLOCK_MAXN = BLOCK_NT / 4;  // 128 nodes
 constexpr int CLQ_M = BLOCK_MAXN / 4;     // clique partners per thread (row 4m + part, m < CLQ_M)
 constexpr int CLQ_NCQ = 12;               // per accepted point: Syy (3 x 3, row-major), tr Syy, n, pad
-constexpr int CLQ_NMOM = 30;              // Sw[3], M[3][3], T3[3], U3[3]; Euclidean targets: R3[3], P[3][3]
+constexpr int CLQ_NMOM = 27;              // Sw[3], M[3][3], T3[3], U3[3] (Euclidean targets: U3 - R3), P[3][3]
 
 // launch-invariant tables of the workgroup-per-problem path (device pointers; gik_template_create)
 struct BlockTabs {
@@ -463,7 +463,7 @@ struct BlockCtx {
     if (!wclq) {
       if ((lane & 15) == 0 && lane < 48) {
 #pragma unroll
-        for (int r = 0; r < 10; ++r) sh_mom[(r * 3 + (lane >> 4)) * BLOCK_WAVES + wave] = 0.0;
+        for (int r = 0; r < 9; ++r) sh_mom[(r * 3 + (lane >> 4)) * BLOCK_WAVES + wave] = 0.0;
       }
       return;
     }
@@ -472,7 +472,8 @@ struct BlockCtx {
     double aw = ytp * w;
     aw += dpp_f64<0xB1>(aw);
     aw += dpp_f64<0x4E>(aw);   // a_j = y~_j . w_j in the four lanes of the node
-    double v[6] = {w, yt[0] * w, yt[1] * w, yt[2] * w, (cm * aw) * ytp, y2t * w};
+    // (with Euclidean targets U3 and R3 = sum r_j w_j only enter as R3 - U3: one register)
+    double v[6] = {w, yt[0] * w, yt[1] * w, yt[2] * w, (cm * aw) * ytp, (lowrank ? y2t - rr : y2t) * w};
 #pragma unroll
     for (int r = 0; r < 6; ++r) v[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[r], 1.0, 0.0, 0, 0, 0);
 #pragma unroll
@@ -484,18 +485,18 @@ struct BlockCtx {
 #pragma unroll
       for (int r = 0; r < 6; ++r) sh_mom[(r * 3 + i) * BLOCK_WAVES + wave] = v[r];
     }
-    if (lowrank) {   // R3[p] = sum r_j w_j[p],  P[p][a] = sum w_j[p] X_j[a]  (index 21 + 3 a + p)
-      double u[4] = {rr * w, Xr[0] * w, Xr[1] * w, Xr[2] * w};
+    if (lowrank) {   // P[p][a] = sum w_j[p] X_j[a]  (index 18 + 3 a + p)
+      double u[3] = {Xr[0] * w, Xr[1] * w, Xr[2] * w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) u[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(u[r], 1.0, 0.0, 0, 0, 0);
+      for (int r = 0; r < 3; ++r) u[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(u[r], 1.0, 0.0, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) u[r] += dpp_f64<0x128>(u[r]);
+      for (int r = 0; r < 3; ++r) u[r] += dpp_f64<0x128>(u[r]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) u[r] += dpp_f64<0x124>(u[r]);
+      for (int r = 0; r < 3; ++r) u[r] += dpp_f64<0x124>(u[r]);
       if ((lane & 15) == 0 && lane < 48) {
         const int i = lane >> 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sh_mom[((6 + r) * 3 + i) * BLOCK_WAVES + wave] = u[r];
+        for (int r = 0; r < 3; ++r) sh_mom[((6 + r) * 3 + i) * BLOCK_WAVES + wave] = u[r];
       }
     }
   }
@@ -523,7 +524,7 @@ struct BlockCtx {
 
   // the O(1)-per-node part of the clique's Hessian-vector product (see the file header), entry
   // `part` of node `node`; call after the barrier that publishes sh_W and sh_mom.
-  // Lanes 0..29 add the eight partials of one moment each; the totals go through a 32-double LDS
+  // Lanes 0..26 add the eight partials of one moment each; the totals go through a 32-double LDS
   // strip of the wave's own and come back as LDS reads instead of 60 v_readlane into scalar
   // registers.
   __device__ inline double clique_closed_form(const double (&wi)[K]) {
@@ -556,12 +557,10 @@ struct BlockCtx {
     const double *mr = strip + 3 + 3 * q;                                     // row q of M: 2 (M y~)_q
     h = fma(ty[2], mr[2], fma(ty[1], mr[1], fma(ty[0], mr[0], h)));
     h = fma(ty[2], sq[9], fma(ty[1], sq[6], fma(ty[0], sq[3], h)));           // column q: 2 (M^T y~)_q
-    h = fma(-2.0, sq[12], h) - sq[15];                                        // - 2 T3_q - U3_q
+    h = fma(-2.0, sq[12], h) - sq[15];                                        // - 2 T3_q - U3_q (+ R3_q)
     h = fma(ytp + ytp, g, h);                                                 // 2 y~_q g
-    if (lowrank) {   // + R3_q - 2 (P X_i)_q,  P[q][a] at 21 + 3 a + q
-      h += sq[18];
-      h = fma(-(Xr[2] + Xr[2]), sq[27], fma(-(Xr[1] + Xr[1]), sq[24], fma(-(Xr[0] + Xr[0]), sq[21], h)));
-    }
+    if (lowrank)     // - 2 (P X_i)_q,  P[q][a] at 18 + 3 a + q
+      h = fma(-(Xr[2] + Xr[2]), sq[24], fma(-(Xr[1] + Xr[1]), sq[21], fma(-(Xr[0] + Xr[0]), sq[18], h)));
     return (node < n_clq && part < 3) ? h : 0.0;
   }
 
