@@ -76,7 +76,8 @@ struct BlockCtx {
   double yt[3], ytp, y2t;      // centred row of the node, own entry, squared norm
   // Euclidean targets: if the clique's D_ij are the squared distances of points X_j in R^3 (any
   // rigid scene), D = r 1^T + 1 r^T - 2 X X^T has rank 5 and (D w)_i = r_i Sw + R3 - 2 P X_i with
-  // R3 = sum r_j w_j, P = sum w_j X_j^T: 12 more moments replace the O(n) product per node
+  // R3 = sum r_j w_j, P = sum w_j X_j^T: 9 more moments (R3 rides with U3) replace the O(n)
+  // product per node
   bool lowrank;                // this problem's clique targets passed the check (block-uniform)
   double Xr[3], rr;            // centred coordinates of the node, squared norm
   double *sh_mom;              // [CLQ_NMOM][BLOCK_WAVES] per-wave partial moments, then
