@@ -473,8 +473,8 @@ struct BlockCtx {
     double aw = ytp * w;
     aw += dpp_f64<0xB1>(aw);
     aw += dpp_f64<0x4E>(aw);   // a_j = y~_j . w_j in the four lanes of the node
-    // Registers (moment index 3 r + p in lane part p): r = 0 Sw, 1..3 M[r-1][.], 4 T3, 5 U3 (with
-    // Euclidean targets U3 and R3 = sum r_j w_j only enter as R3 - U3: one register), 6..8 P[.][r-6].
+    // Registers: 0 Sw, 1..3 M[r-1][.], 4 U3 (with Euclidean targets U3 and R3 = sum r_j w_j only
+    // enter as R3 - U3: one register), 5..7 P[.][r-5]; lane part p holds the entry of column p.
     // Eight of them are folded by transposing exchanges, as in wave_sum_n<8>: v_permlane32_swap
     // puts the upper half of one register next to the lower half of another, so one add folds
     // lane rows (0, 2) and (1, 3) of TWO registers; v_permlane16_swap does the same for the
@@ -483,11 +483,14 @@ struct BlockCtx {
     // preserved throughout; two row rotations add the four quads.  30 instructions for eight
     // registers instead of eight MFMAs + 48 (an f64 MFMA occupies the matrix pipe ~16 cycles and
     // the two waves of a SIMD share it).
+    // (T3[a] = sum a_j y~_j[a] rides in the idle fourth lane of register 1 + a)
+    const double wsel = part == 3 ? (node < n_clq ? aw : 0.0) : w;
     double v[8];
-    v[0] = w; v[1] = yt[0] * w; v[2] = yt[1] * w; v[3] = yt[2] * w; v[4] = (cm * aw) * ytp;
-    v[5] = (lowrank ? y2t - rr : y2t) * w;
-    v[6] = lowrank ? Xr[0] * w : 0.0;
-    v[7] = lowrank ? Xr[1] * w : 0.0;
+    v[0] = w; v[1] = yt[0] * wsel; v[2] = yt[1] * wsel; v[3] = yt[2] * wsel;
+    v[4] = (lowrank ? y2t - rr : y2t) * w;
+    v[5] = lowrank ? Xr[0] * w : 0.0;
+    v[6] = lowrank ? Xr[1] * w : 0.0;
+    v[7] = lowrank ? Xr[2] * w : 0.0;
 #pragma unroll
     for (int q = 0; q < 8; q += 2) {
       lane_swap32(v[q], v[q + 1]);
@@ -502,17 +505,16 @@ struct BlockCtx {
       v[q] += dpp_f64<0x128>(v[q]);   // row_ror:8
       v[q] += dpp_f64<0x124>(v[q]);   // row_ror:4
     }
-    if ((lane & 12) == 0 && part < 3) {   // quad 0 of every lane row: row rho holds register {0, 2, 1, 3}[rho]
+    if ((lane & 12) == 0) {   // quad 0 of every lane row: row rho holds register {0, 2, 1, 3}[rho] (+ 4)
       const int rho = lane >> 4;
       const int reg = ((rho & 1) << 1) | (rho >> 1);
-      sh_mom[(reg * 3 + part) * BLOCK_WAVES + wave] = v[0];
-      sh_mom[((4 + reg) * 3 + part) * BLOCK_WAVES + wave] = v[4];
-    }
-    if (lowrank) {   // the ninth register, P[.][2]: MFMA cross-row sum (B = 1), then the quads
-      double u = __builtin_amdgcn_mfma_f64_4x4x4f64(Xr[2] * w, 1.0, 0.0, 0, 0, 0);
-      u += dpp_f64<0x128>(u);
-      u += dpp_f64<0x124>(u);
-      if ((lane & 15) == 0 && lane < 48) sh_mom[(8 * 3 + (lane >> 4)) * BLOCK_WAVES + wave] = u;
+      // moment index: Sw[p] = p, M[a][p] = 3 + 3a + p, T3[a] = 12 + a, U3[p] = 15 + p, P[p][a] = 18 + 3a + p
+      if (part < 3) {
+        sh_mom[(reg * 3 + part) * BLOCK_WAVES + wave] = v[0];
+        sh_mom[((5 + reg) * 3 + part) * BLOCK_WAVES + wave] = v[4];
+      } else if (reg > 0) {
+        sh_mom[(12 + reg - 1) * BLOCK_WAVES + wave] = v[0];
+      }
     }
   }
 
