@@ -1001,14 +1001,28 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
       wave_sl[2 * w] = std::max(wave_sl[2 * w], (int)eqs[tid].size());
       wave_sl[2 * w + 1] = std::max(wave_sl[2 * w + 1], (int)hinges[tid].size());
     }
+    // A wavefront with few slots runs them as ONE kind-decoding loop over each thread's equality
+    // terms followed by its hinge terms ({0, T_w}: T_w = most terms of any of its threads) when that
+    // is shorter than the padded split loops (table scene: 1 + 1 -> 1 for the base / goal nodes,
+    // 3 + 1 -> 3 for the free nodes; an iteration is two dependent LDS round trips).
+    std::vector<char> merged(BLOCK_WAVES, 0);
     for (int w = 0; w < BLOCK_WAVES; ++w) {
-      wave_sl[2 * w + 1] += wave_sl[2 * w];   // {SLE_w, SL_w}
+      int tot = 0;
+      for (int tid = w * WAVE; tid < (w + 1) * WAVE; ++tid)
+        tot = std::max(tot, (int)(eqs[tid].size() + hinges[tid].size()));
+      if (tot <= 8 && tot < wave_sl[2 * w] + wave_sl[2 * w + 1]) {
+        merged[w] = 1;
+        wave_sl[2 * w] = 0;
+        wave_sl[2 * w + 1] = tot;
+      } else {
+        wave_sl[2 * w + 1] += wave_sl[2 * w];   // {SLE_w, SL_w}
+      }
       SLE = std::max(SLE, wave_sl[2 * w]);
       SL = std::max(SL, wave_sl[2 * w + 1]);
     }
     meta.assign((size_t)std::max(SL, 1) * BLOCK_NT, 0);
     for (int tid = 0; tid < BLOCK_NT; ++tid) {
-      const int node = tid >> 2, sle = wave_sl[2 * (tid / WAVE)];
+      const int node = tid >> 2, w = tid / WAVE, sle = merged[w] ? (int)eqs[tid].size() : wave_sl[2 * w];
       for (int s = 0; s < SL; ++s) {
         uint32_t m = meta_pack(node_of_row[node] >= 0 ? node : 0, 0, 0, 0);
         const std::vector<Ent> &src = s < sle ? eqs[tid] : hinges[tid];
