@@ -252,11 +252,19 @@ struct BlockCtx {
   template <int NV>
   __device__ inline void sum_n(double (&v)[NV]) {
     static_assert(NV <= 8, "reduction scratch holds 8 values");
-    wave_sum_n<NV>(v);  // wave totals, uniform within the wave
     double *buf = sh_red + red_buf * 8 * BLOCK_WAVES;
-    if (lane == 0) {
+    if constexpr (NV == 8) {
+      // the lanes that hold the eight wave totals store them: one exec-masked write instead of
+      // sixteen v_readlane and eight writes from lane 0
+      const double w = wave_sum8_distributed(v);
+      const int q = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2);
+      if ((lane & 7) == 0) buf[q * BLOCK_WAVES + wave] = w;
+    } else {
+      wave_sum_n<NV>(v);  // wave totals, uniform within the wave
+      if (lane == 0) {
 #pragma unroll
-      for (int q = 0; q < NV; ++q) buf[q * BLOCK_WAVES + wave] = v[q];
+        for (int q = 0; q < NV; ++q) buf[q * BLOCK_WAVES + wave] = v[q];
+      }
     }
     __syncthreads();
     // cross-wave step: lane 8q + w fetches the total of wave w for value q (one LDS read per

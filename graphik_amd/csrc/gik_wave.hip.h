@@ -210,8 +210,8 @@ __device__ inline void lane_swap16(double &a, double &b) {
   a = __hiloint2double((int)s[0], (int)r[0]);
   b = __hiloint2double((int)s[1], (int)r[1]);
 }
-template <>
-__device__ inline void wave_sum_n<8>(double (&v)[8]) {
+// the eight wave totals, still distributed: value q in the lanes with (bit5, bit4, bit3) = (q&1, q&2, q&4)
+__device__ inline double wave_sum8_distributed(double (&v)[8]) {
 #pragma unroll
   for (int q = 0; q < 8; q += 2) {
     lane_swap32(v[q], v[q + 1]);
@@ -226,6 +226,11 @@ __device__ inline void wave_sum_n<8>(double (&v)[8]) {
   w += dpp_f64<0xB1>(w);   // quad_perm [1,0,3,2]
   w += dpp_f64<0x4E>(w);   // quad_perm [2,3,0,1]
   w += dpp_f64<0x141>(w);  // row_half_mirror
+  return w;
+}
+template <>
+__device__ inline void wave_sum_n<8>(double (&v)[8]) {
+  const double w = wave_sum8_distributed(v);
 #pragma unroll
   for (int q = 0; q < 8; ++q)
     v[q] = readlane_f64(w, ((q & 1) ? 32 : 0) + ((q & 2) ? 16 : 0) + ((q & 4) ? 8 : 0));
