@@ -264,6 +264,7 @@ struct PrepArgs {
   double *dbg_lb, *dbg_ub;  // [B][N*N]
   double *dbg_eig;          // [B][3][N]
   int B, sweeps;
+  int stop_phase;        // developer build only (GIK_PREP_STOP): leave a goal after phase p (timing)
 };
 
 __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
@@ -662,6 +663,9 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       const double g = src >= 0 ? gd[src] : 0.0;
       a.targets[(size_t)b * pc.T + t] = src >= 0 ? g * g : pc.term_static[t];
     }
+#ifdef GIK_DEV
+    if (a.stop_phase == 1) continue;
+#endif
     // ---- bound smoothing (see prep_wave_kernel)
     for (int m = 0; m < N; ++m) {
       for (int e = tid; e < NN; e += PREP_NT) {
@@ -671,6 +675,9 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       }
       __syncthreads();
     }
+#ifdef GIK_DEV
+    if (a.stop_phase == 2) continue;
+#endif
     for (int e = tid; e < NN; e += PREP_NT) {  // A[u][b] = max_a (L[a][b] - U[u][a])
       const int u = e / N, bb = e - u * N;
       double best = -INFINITY;
@@ -685,6 +692,9 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       V[e] = best;
     }
     __syncthreads();
+#ifdef GIK_DEV
+    if (a.stop_phase == 3) continue;
+#endif
     if (a.dbg_lb)
       for (int e = tid; e < NN; e += PREP_NT) {
         a.dbg_lb[(size_t)b * NN + e] = V[e];
@@ -711,7 +721,13 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       V[e] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
+#ifdef GIK_DEV
+    if (a.stop_phase == 4) continue;
+#endif
     jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid);
+#ifdef GIK_DEV
+    if (a.stop_phase == 5) continue;
+#endif
     // ---- factor(): clip, scale by sqrt(lambda), order descending
     __syncthreads();
     if (tid < N) ev[tid] = A[tid * N + tid];
@@ -741,6 +757,9 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       A[e] = (i >= j) ? X[i * N + j] : X[j * N + i];
     }
     __syncthreads();
+#ifdef GIK_DEV
+    if (a.stop_phase == 6) continue;
+#endif
     if (a.dbg_eig) {   // diagnostics only: the spectrum itself, then A is rebuilt for the count
       jacobi_blk(A, nullptr, N, a.sweeps, cs, pq, red, tid);
       __syncthreads();
@@ -755,6 +774,9 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
     const int Kc = count_eigs_above_blk(A, N, 1e-8, ev, sg, red, tid);
     if (a.K_out && tid == 0) a.K_out[b] = Kc;
     __syncthreads();
+#ifdef GIK_DEV
+    if (a.stop_phase == 7) continue;
+#endif
     // ---- linear_projection (dgp.py:174-183)
     for (int e = tid; e < NN; e += PREP_NT) {
       const int c = e % N;
@@ -772,22 +794,42 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       double acc[CPT];
 #pragma unroll
       for (int q = 0; q < CPT; ++q) acc[q] = 0.0;
+      // Columns >= Kc of X are zero, hence so are the edge differences there and every entry of S
+      // outside its leading Kc x Kc block (Kc ~ 30 of 116 on the table scene): only that block is
+      // accumulated -- same products in the same order for the entries that are not zero.
+      const int nq = (Kc + 3) >> 2;                  // column groups c0 + 4 q that reach below Kc
+      const bool row_live = r < Kc;
+      const int kw = 4 * nq;                         // staged columns: [0, Kc) and the zero pad up to 4 nq
+      // The work-matrix buffer is free until S is written: it holds X's first kw columns (row
+      // stride kw) for the edge differences -- out of the slab these were two dependent loads
+      // through the L2 / Infinity Cache per staged value, 55 ms of the 236 per 4096 table-scene goals.
+      double *XL = A;
+      for (int e = tid; e < N * kw; e += PREP_NT) {
+        const int i = e / kw, c = e - i * kw;
+        XL[e] = c < Kc ? X[i * N + c] : 0.0;
+      }
+      __syncthreads();
       for (int p0 = 0; p0 < pc.n_pairs; p0 += PREP_PC) {
         const int np_ = min(PREP_PC, pc.n_pairs - p0);
-        for (int it = tid; it < np_ * PREP_MAXN; it += PREP_NT) {
-          const int pp = it / PREP_MAXN, c = it - pp * PREP_MAXN;
-          double dv = 0.0;
-          if (c < N) {
-            const int i = pc.pair_i[p0 + pp], j = pc.pair_j[p0 + pp];
-            dv = X[i * N + c] - X[j * N + c];
-          }
-          dl[it] = dv;
+        for (int it = tid; it < np_ * kw; it += PREP_NT) {
+          const int pp = it / kw, c = it - pp * kw;
+          const int i = pc.pair_i[p0 + pp], j = pc.pair_j[p0 + pp];
+          dl[pp * PREP_MAXN + c] = XL[i * kw + c] - XL[j * kw + c];
         }
         __syncthreads();
-        for (int pp = 0; pp < np_; ++pp) {
-          const double dr = dl[pp * PREP_MAXN + r];
+        if (row_live) {
+          // column groups outermost (one uniform branch per group of four columns, the pair loop
+          // inside it): a guard per column made every product wait for its own LDS read
 #pragma unroll
-          for (int q = 0; q < CPT; ++q) acc[q] = fma(dr, dl[pp * PREP_MAXN + c0 + 4 * q], acc[q]);
+          for (int g = 0; g < CPT / 4; ++g) {
+            if (4 * g >= nq) continue;
+#pragma unroll 4
+            for (int pp = 0; pp < np_; ++pp) {
+              const double dr = dl[pp * PREP_MAXN + r];
+#pragma unroll
+              for (int q = 4 * g; q < 4 * g + 4; ++q) acc[q] = fma(dr, dl[pp * PREP_MAXN + c0 + 4 * q], acc[q]);
+            }
+          }
         }
         __syncthreads();
       }
@@ -799,8 +841,14 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       for (int e = tid; e < NN; e += PREP_NT) V[e] = ((e / N) == (e % N)) ? 1.0 : 0.0;
     }
     __syncthreads();
+#ifdef GIK_DEV
+    if (a.stop_phase == 8) continue;
+#endif
     jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid, Kc > 1 ? Kc : 2);
     __syncthreads();
+#ifdef GIK_DEV
+    if (a.stop_phase == 9) continue;
+#endif
     if (tid < N) ev[tid] = (tid < Kc) ? A[tid * N + tid] : -INFINITY;
     if (a.dbg_eig && tid < N) a.dbg_eig[((size_t)b * 3 + 2) * N + tid] = (tid < Kc) ? A[tid * N + tid] : 0.0;
     __syncthreads();

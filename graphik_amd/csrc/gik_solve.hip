@@ -1354,6 +1354,10 @@ int gik_prepare_batch_debug(const gik_template *t, const double *d_T_goal, int B
   if ((a.dbg_lb == nullptr) != (a.dbg_ub == nullptr)) return fail("d_lb and d_ub go together");
   a.B = B;
   a.sweeps = t->sweeps;
+  a.stop_phase = 0;
+#ifdef GIK_DEV
+  if (const char *e = getenv("GIK_PREP_STOP")) a.stop_phase = atoi(e);   // developer build: timing of the phases
+#endif
   const int grid = std::min(B, t->n_cu * t->prep_waves_per_cu);
   if (t->prep_block) {
     gik_template *mt = const_cast<gik_template *>(t);   // the workspace hand-over is the mutable part
