@@ -477,13 +477,91 @@ __device__ inline double prep_block_sum(double x, double *red, int tid) {
   return s;
 }
 
-// cyclic Jacobi, round-robin order, block-wide (see jacobi_lds for the arithmetic)
+// cyclic Jacobi, round-robin order, block-wide (see jacobi_lds for the arithmetic).
+// Eigenvectors: V lives in the global slab, and rotating its columns round by round reads and
+// writes the whole matrix 115 times per sweep (0.8 TB through the L2 per 4096 table-scene goals,
+// the bulk of the kernel).  With a log buffer (`vlog`, 28 KB of LDS) the rounds only rotate A and
+// record their (c, s, p, q); every JLOG_ROUNDS rotated rounds the log is applied to V row by row
+// -- a wavefront keeps two rows in LDS, runs the logged rounds over it (the pairs of a round are
+// disjoint: 58 lanes in parallel, rounds in order) and writes it back -- so V is read and written
+// once per 12 rounds.  Every element still goes through the same rotations in the same order:
+// bit-identical to the round-by-round version (and to the wavefront kernel).
+constexpr int JLOG_ROUNDS = 12;
+constexpr int JLOG_DOUBLES = JLOG_ROUNDS * PREP_MAXN + JLOG_ROUNDS * (PREP_MAXN / 2) / 2 + 2 * (PREP_NT / 64) * PREP_MAXN;
+
+__device__ inline void jacobi_apply_log(double *V, int stride, int n, int np, int nlog, const double *cs_log,
+                                        const int *pq_log, double *rows, int tid) {
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  // two rows per wavefront at a time (the rounds of a row are a chain of dependent LDS round
+  // trips, two independent chains overlap), and the next two rows are requested from the slab
+  // into registers before the rounds of the current ones start: a row costs two trips through
+  // the L2 / Infinity Cache, which would otherwise sit between any two row pairs of a wavefront
+  double *rb0 = rows + (2 * wave) * PREP_MAXN, *rb1 = rb0 + PREP_MAXN;
+  const int c0 = lane, c1 = lane + 64;
+  const bool h0 = c0 < n, h1 = c1 < n;
+  constexpr int STEP = 2 * (PREP_NT / 64);
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+  auto fetch = [&](int row) {
+    if (row < n) {
+      if (h0) a0 = V[row * stride + c0];
+      if (h1) a1 = V[row * stride + c1];
+      if (row + 1 < n) {
+        if (h0) b0 = V[(row + 1) * stride + c0];
+        if (h1) b1 = V[(row + 1) * stride + c1];
+      }
+    }
+  };
+  fetch(2 * wave);
+  for (int row = 2 * wave; row < n; row += STEP) {
+    const bool two = row + 1 < n;
+    if (h0) { rb0[c0] = a0; rb1[c0] = b0; }
+    if (h1) { rb0[c1] = a1; rb1[c1] = b1; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    fetch(row + STEP);
+    for (int k = 0; k < nlog; ++k) {
+      if (lane < np) {
+        const int code = pq_log[k * (PREP_MAXN / 2) + lane];
+        if (code >= 0) {
+          const int p = code & 0xff, q = code >> 8;
+          const double c = cs_log[k * PREP_MAXN + 2 * lane], s = cs_log[k * PREP_MAXN + 2 * lane + 1];
+          const double ap = rb0[p], aq = rb0[q], bp = rb1[p], bq = rb1[q];
+          rb0[p] = c * ap - s * aq;
+          rb0[q] = s * ap + c * aq;
+          rb1[p] = c * bp - s * bq;
+          rb1[q] = s * bp + c * bq;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (h0) V[row * stride + c0] = rb0[c0];
+    if (h1) V[row * stride + c1] = rb0[c1];
+    if (two) {
+      if (h0) V[(row + 1) * stride + c0] = rb1[c0];
+      if (h1) V[(row + 1) * stride + c1] = rb1[c1];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // rb is rewritten at the top of the loop
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+}
+
 __device__ inline void jacobi_blk(double *A, double *V, int N, int sweeps, double *cs, int *pq,
-                                  double *red, int tid, int n = -1) {
+                                  double *red, int tid, int n = -1, double *vlog = nullptr) {
   if (n < 0) n = N;
   const int stride = N;
   N = n;
   const int ne = N + (N & 1), np = ne / 2;
+  double *cs_log = vlog;
+  int *pq_log = reinterpret_cast<int *>(vlog + JLOG_ROUNDS * PREP_MAXN);
+  double *rows = vlog + JLOG_ROUNDS * PREP_MAXN + JLOG_ROUNDS * (PREP_MAXN / 2) / 2;   // two rows per wavefront
+  const bool logged = V != nullptr && vlog != nullptr;
+  int nlog = 0;
+  // quotient / remainder of the thread's first item and of the stride, for both item orders
+  const int col_i0 = tid / np, col_m0 = tid - col_i0 * np, col_dq = PREP_NT / np, col_dr = PREP_NT - col_dq * np;
+  const int row_m0 = tid / N, row_i0 = tid - row_m0 * N, row_dq = PREP_NT / N, row_dr = PREP_NT - row_dq * N;
   double fro = 0.0;
   for (int e = tid; e < N * N; e += PREP_NT) {
     const int i = e / N, j = e - i * N;
@@ -515,6 +593,11 @@ __device__ inline void jacobi_blk(double *A, double *V, int N, int sweeps, doubl
         cs[2 * tid] = c;
         cs[2 * tid + 1] = s;
         pq[tid] = code;
+        if (logged) {   // slot nlog is overwritten by the next round if this one rotates nothing
+          cs_log[nlog * PREP_MAXN + 2 * tid] = c;
+          cs_log[nlog * PREP_MAXN + 2 * tid + 1] = s;
+          pq_log[nlog * (PREP_MAXN / 2) + tid] = code;
+        }
       }
       if (!__syncthreads_or(sig)) continue;   // nothing to rotate in this round
       rotated = true;
@@ -522,22 +605,33 @@ __device__ inline void jacobi_blk(double *A, double *V, int N, int sweeps, doubl
       // (consecutive threads take the rotations of ONE row: its 2 np entries lie in a few cache
       // lines, whereas consecutive rows of one column are N doubles apart -- 64 lines per wave)
       // (A and V in loops of their own: A may live in LDS, and each loop then has one address space)
+      // (item `it` = (row idx, pair m) = (it / np, it % np): the quotient and remainder are
+      // stepped, not divided -- an integer division by a run-time divisor is ~40 instructions, more
+      // than the rotation itself, and there were 26 of them per thread and round)
       const int per = np * N;
-      for (int it = tid; it < per; it += PREP_NT) {
-        const int idx = it / np, m = it - idx * np;
-        const int code = pq[m];
-        if (code >= 0) {
-          const int p = code & 0xff, q = code >> 8;
-          const double c = cs[2 * m], s = cs[2 * m + 1];
-          const double ap = A[idx * stride + p], aq = A[idx * stride + q];
-          A[idx * stride + p] = c * ap - s * aq;
-          A[idx * stride + q] = s * ap + c * aq;
+      {
+        int idx = col_i0, m = col_m0;
+        for (int it = tid; it < per; it += PREP_NT) {
+          const int code = pq[m];
+          if (code >= 0) {
+            const int p = code & 0xff, q = code >> 8;
+            const double c = cs[2 * m], s = cs[2 * m + 1];
+            const double ap = A[idx * stride + p], aq = A[idx * stride + q];
+            A[idx * stride + p] = c * ap - s * aq;
+            A[idx * stride + q] = s * ap + c * aq;
+          }
+          idx += col_dq;
+          m += col_dr;
+          if (m >= np) {
+            m -= np;
+            ++idx;
+          }
         }
       }
-      if (V != nullptr) {
+      if (V != nullptr && !logged) {
+        int idx = col_i0, m = col_m0;
 #pragma unroll 2
         for (int it = tid; it < per; it += PREP_NT) {
-          const int idx = it / np, m = it - idx * np;
           const int code = pq[m];
           if (code >= 0) {
             const int p = code & 0xff, q = code >> 8;
@@ -546,25 +640,44 @@ __device__ inline void jacobi_blk(double *A, double *V, int N, int sweeps, doubl
             V[idx * stride + p] = c * ap - s * aq;
             V[idx * stride + q] = s * ap + c * aq;
           }
+          idx += col_dq;
+          m += col_dr;
+          if (m >= np) {
+            m -= np;
+            ++idx;
+          }
         }
       }
       __syncthreads();
       // row phase on A: rows p, q of every column
-      for (int it = tid; it < per; it += PREP_NT) {
-        const int m = it / N, idx = it - m * N;
-        const int code = pq[m];
-        if (code >= 0) {
-          const int p = code & 0xff, q = code >> 8;
-          const double c = cs[2 * m], s = cs[2 * m + 1];
-          const double ap = A[p * stride + idx], aq = A[q * stride + idx];
-          A[p * stride + idx] = c * ap - s * aq;
-          A[q * stride + idx] = s * ap + c * aq;
+      {
+        int m = row_m0, idx = row_i0;
+        for (int it = tid; it < per; it += PREP_NT) {
+          const int code = pq[m];
+          if (code >= 0) {
+            const int p = code & 0xff, q = code >> 8;
+            const double c = cs[2 * m], s = cs[2 * m + 1];
+            const double ap = A[p * stride + idx], aq = A[q * stride + idx];
+            A[p * stride + idx] = c * ap - s * aq;
+            A[q * stride + idx] = s * ap + c * aq;
+          }
+          m += row_dq;
+          idx += row_dr;
+          if (idx >= N) {
+            idx -= N;
+            ++m;
+          }
         }
       }
       __syncthreads();
+      if (logged && ++nlog == JLOG_ROUNDS) {
+        jacobi_apply_log(V, stride, N, np, nlog, cs_log, pq_log, rows, tid);
+        nlog = 0;
+      }
     }
     if (!rotated) break;
   }
+  if (logged && nlog) jacobi_apply_log(V, stride, N, np, nlog, cs_log, pq_log, rows, tid);
 }
 
 // count_eigs_above_lds for the workgroup-per-goal kernel: A in global memory (row stride N), v / w in
@@ -625,7 +738,8 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
   __shared__ double cs[2 * (PREP_MAXN / 2)];
   __shared__ double ev[PREP_MAXN], sg[PREP_MAXN], red[PREP_NT / 64];
   __shared__ int pq[PREP_MAXN / 2], rk[PREP_MAXN];
-  __shared__ double dl[PREP_PC * PREP_MAXN];    // edge differences of PREP_PC pairs
+  __shared__ double dl[PREP_PC * PREP_MAXN];    // edge differences of PREP_PC pairs; Jacobi rotation log
+  static_assert(JLOG_DOUBLES <= PREP_PC * PREP_MAXN, "the rotation log shares the scatter phase's tile buffer");
   const PipeConst &pc = a.pc;
   const int N = pc.N, K = pc.K, NN = N * N, tid = threadIdx.x;
   double *Ug = ws + (size_t)blockIdx.x * 5 * NN;
@@ -724,7 +838,7 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
 #ifdef GIK_DEV
     if (a.stop_phase == 4) continue;
 #endif
-    jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid);
+    jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid, -1, dl);
 #ifdef GIK_DEV
     if (a.stop_phase == 5) continue;
 #endif
@@ -844,7 +958,7 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
 #ifdef GIK_DEV
     if (a.stop_phase == 8) continue;
 #endif
-    jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid, Kc > 1 ? Kc : 2);
+    jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid, Kc > 1 ? Kc : 2, dl);
     __syncthreads();
 #ifdef GIK_DEV
     if (a.stop_phase == 9) continue;
