@@ -660,11 +660,15 @@ def test_end_to_end_statistics_from_device_init(torch_cuda, name):
     assert 0.7 < np.median(pos) / np.median(pos_o) < 1.4
 
 
-@pytest.mark.parametrize("name", ["lwa4d", "planar10_limits_halfpi"])
-def test_block_prepare_kernel_equals_wave_kernel(torch_cuda, monkeypatch, name):
+@pytest.mark.parametrize("name,a_global", [("lwa4d", False), ("lwa4d", True), ("planar10_limits_halfpi", False)])
+def test_block_prepare_kernel_equals_wave_kernel(torch_cuda, monkeypatch, name, a_global):
     """The workgroup-per-goal prepare kernel (graphs beyond one wavefront's LDS) performs the same
     operations in the same order per matrix element as the wavefront kernel, so on a graph both can
-    take, targets, initial points and MDS ranks agree bit for bit."""
+    take, targets, initial points and MDS ranks agree bit for bit -- with its work matrix in LDS
+    (N <= 123) and with it in the global slab (GIK_PREP_A_GLOBAL, read at attach: the variant
+    graphs of 124..128 nodes get)."""
+    if a_global:
+        monkeypatch.setenv("GIK_PREP_A_GLOBAL", "1")
     from graphik_amd.solvers.riemannian_solver import BatchProblem
     robot, graph = make_graph(name)
     rng = np.random.RandomState(8)
