@@ -89,6 +89,8 @@ def parse_args(argv=None):
                     help="ur10_table only: the opt-in fixed-anchor formulation with the robot<->obstacle "
                          "hinges the reference means to create (SURVEY 8(f)3); NOT the reference's observable "
                          "semantics and not the BASELINE line")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="default invocation: skip the c3 / c4 / c5 measurements that follow the headline")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"])
     ap.add_argument("--dry-solve", action="store_true",
                     help="no GPU: deterministic stand-in for the solve (tests of the N>1 logic)")
@@ -200,266 +202,369 @@ def cpu_baseline(prob, T_goal, Y0_h, B, args):
     }
 
 
+def executed_flops(N, k, T, info, lowrank_frac, n_inner, n_outer, n_accept):
+    """Flops the solve kernel EXECUTES.  Wavefront kernel: the algorithmic count
+    (every term is evaluated once per product).  Workgroup kernel with a rigid clique of n nodes
+    in closed form: per Hessian product the T_rest terms left in the per-term loops (12 k each),
+    the moments (18, or 27 with Euclidean targets: one multiply + one add per clique node each),
+    the closed form itself (58 flops per clique unknown, 49 without the low-rank D w part) and,
+    without Euclidean targets, the dense D w product (2 n flops per clique unknown); cost and
+    gradient walk every term as the algorithmic count says."""
+    n = int(info.get("n_clique", 0)) if info else 0
+    if n == 0:
+        return algorithmic_flops(N, k, T, n_inner, n_outer, n_accept)
+    T_rest = int(info["n_slot_terms"])
+    hv_low = 12 * k * T_rest + 27 * 2 * n + 58 * 3 * n
+    hv_dense = 12 * k * T_rest + 18 * 2 * n + 49 * 3 * n + 2 * n * 3 * n
+    hv = lowrank_frac * hv_low + (1.0 - lowrank_frac) * hv_dense
+    F_hv = hv + (4 * N * k * k + k * k + 2 * k ** 4) + 16 * N * k
+    F_cost = (3 * k + 6) * T + 5 * N * k
+    F_acc = 9 * k * T + N * k * (k + 1) + (2.0 / 3.0) * k ** 6
+    return n_inner * F_hv + n_outer * F_cost + n_accept * F_acc
+
+
+class Bench:
+    """One process = one rank = one GPU.  `measure()` times one workload (a BASELINE config) on this
+    rank's shard and returns the report dict on rank 0 (None elsewhere)."""
+
+    def __init__(self, args):
+        import torch
+        from graphik_amd import distributed as gd
+        self.args, self.torch, self.gd = args, torch, gd
+        backend = args.backend or ("gloo" if args.dry_solve else None)
+        self.rank, self.local_rank, self.world = gd.init_process_group(backend=backend)
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {self.world} rank(s); "
+                             f"run `python bench.py --gpus {args.gpus}` (self-launching) or "
+                             f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py "
+                             f"--gpus {args.gpus}`")
+        self.dry = args.dry_solve
+        if not self.dry:
+            assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+        else:
+            self.dev = torch.device("cpu")
+
+    # -- goals: rank r draws rows shard_range(total, r, world) of ONE global random stream --------
+    def goals(self, robot, total, seed):
+        lo, hi = self.gd.shard_range(total, self.rank, self.world)
+        rs = np.random.RandomState(seed)
+        U = rs.rand(total, robot.n)[lo:hi]
+        lb, ub = robot.limits_arrays()
+        return robot.fk_batch(lb + (ub - lb) * U), hi - lo
+
+    def measure_dry(self, cfg, robot_name, total, scaling, steps, warmup):
+        gd, torch = self.gd, self.torch
+        robot, graph = build_graph(robot_name)
+        T_goal, B = self.goals(robot, total, self.args.seed)
+        for _ in range(warmup):
+            st = dry_results(T_goal)
+        gd.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st = dry_results(T_goal)
+        gd.barrier()
+        dt = gd.max_over_ranks(time.perf_counter() - t0, self.dev)
+        allstats = gd.gather_rows(torch.from_numpy(st), total, dst=0)
+        if self.rank != 0:
+            return None
+        a = allstats.numpy()
+        return {
+            "metric": "IK solves/sec (batched random goals)", "value": None, "unit": "solves/s",
+            "dry_solve": True, "n_gpus": self.world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "scaling": scaling,
+            "config": {"workload": f"{robot_name}, {total} goals over {self.world} rank(s)",
+                       "config": cfg, "robot": robot_name, "goals_total": total},
+            "rows": int(a.shape[0]), "checksum": float(a.sum()),
+            "rows_sha": __import__("hashlib").sha256(np.ascontiguousarray(a).tobytes()).hexdigest(),
+        }
+
+    def measure(self, cfg, robot_name, total, scaling, steps, warmup, serving_streams=0,
+                cpu=False, streams=1, intended=False):
+        if self.dry:
+            return self.measure_dry(cfg, robot_name, total, scaling, steps, warmup)
+        args, torch, gd, dev, rank, world = self.args, self.torch, self.gd, self.dev, self.rank, self.world
+        robot, graph = build_graph(robot_name)
+        T_goal, B = self.goals(robot, total, args.seed)
+        from graphik_amd.solvers.riemannian_solver import AnchoredProblem, BatchProblem
+        anch = None
+        if intended:
+            if robot_name != "ur10_table":
+                raise SystemExit("--intended applies to --config c3 / --robot ur10_table")
+            anch = AnchoredProblem(graph, device=dev)
+            prob = anch.base
+            N, k = len(anch.free), 3
+            T = anch.template.T + len(anch.pin)              # terms the Hessian product sees
+        else:
+            prob = BatchProblem(graph, use_limits=True, device=dev)
+            N, k, T = graph.number_of_nodes(), graph.dim, prob.template.T
+        tpl = prob.template
+        on_device = prob.device_pipeline
+        Tg_dev = torch.from_numpy(T_goal).to(dev)        # inputs resident in HBM
+        if not on_device:
+            tg_h, Y0_h0 = prob.prepare(T_goal)
+            tg_dev, Y0_dev = torch.from_numpy(tg_h).to(dev), torch.from_numpy(Y0_h0).to(dev)
+        torch.cuda.synchronize(dev)
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+
+        anch_ms = []
+
+        def step(i=None):
+            """goal poses -> joint angles + pose errors, entirely on the device: prepare
+            (from_pose, bound smoothing, MDS init) -> RTR solve -> recover (joint_variables, FK)."""
+            if anch is not None:        # fixed-anchor pipeline: one C call (prepare, fit, solve, gather, recover)
+                res = anch.template.anchored_ik(tpl, Tg_dev)
+                if i is not None:
+                    anch_ms.append(anch.template)
+                res.update(Y0=res["x"])
+                return res
+            targets, Y0 = tpl.prepare(Tg_dev) if on_device else (tg_dev, Y0_dev)
+            if i is not None:
+                ev0[i].record()      # all kernels are launched on torch's current stream
+            res = tpl.solve(Y0, targets)
+            if i is not None:
+                ev1[i].record()
+            if on_device:
+                q, pe, re = tpl.recover(res["x"], Tg_dev)
+                res.update(q=q, pos_err=pe, rot_err=re)
+            res.update(Y0=Y0)
+            return res
+
+        for _ in range(warmup):
+            res = step()
+        torch.cuda.synchronize(dev)
+        gd.barrier()
+        torch.cuda.synchronize(dev)
+        streams = [torch.cuda.Stream(dev) for _ in range(streams)] if streams > 1 else None
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if streams is None:
+                res = step(i)
+            else:                      # every step is the same full batch; S of them are in flight
+                with torch.cuda.stream(streams[i % streams]):
+                    res = step(i)
+        torch.cuda.synchronize(dev)
+        gd.barrier()
+        dt_local = time.perf_counter() - t0
+        dt = gd.max_over_ranks(dt_local, dev)
+        if anch is not None:
+            # The events around the anchored solve kernel live inside the C call and reading them waits
+            # for it, so the per-step kernel time is taken in a pass of its own AFTER the timed region
+            # (same inputs, `steps` launches, mean).
+            ks = []
+            for _ in range(steps):
+                step()
+                ks.append(float(anch.template.lib.gik_anchored_last_solve_ms(anch.template._h)))
+            kernel_ms = float(np.mean(ks))
+        else:
+            kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+
+        # Serving configuration, reported separately (NOT `value`): the same batches, S in flight on
+        # separate HIP streams, so the straggler tail of one batch overlaps with the bulk of the next.
+        serving = None
+        S = serving_streams
+        if S > 1 and streams == 1 and dt / steps < 0.5:   # (skipped for multi-second batches)
+            nb = 4 * S
+            sv_streams = [torch.cuda.Stream(dev) for _ in range(S)]
+            for s_ in sv_streams:                        # warm the per-stream allocations
+                with torch.cuda.stream(s_):
+                    step()
+            torch.cuda.synchronize(dev)
+            gd.barrier()
+            ts = time.perf_counter()
+            for i in range(nb):
+                with torch.cuda.stream(sv_streams[i % S]):
+                    step()
+            torch.cuda.synchronize(dev)
+            gd.barrier()
+            dts = gd.max_over_ranks(time.perf_counter() - ts, dev)
+            serving = {"value": total * nb / dts, "unit": "solves/s", "batches_in_flight": S,
+                       "batches": nb, "ms_per_batch": dts / nb * 1e3,
+                       "note": "same workload and kernels as `value`; S batches in flight on separate HIP "
+                               "streams (a serving configuration: independent requests overlap, the "
+                               "straggler tail of one batch runs beside the bulk of the next)"}
+
+        if not on_device:   # host post-processing, after the timed region
+            qh = prob.joint_variables(res["x"].cpu().numpy(), T_goal)
+            pe, re = prob.pose_errors(qh, T_goal)
+            res.update(pos_err=torch.from_numpy(pe).to(dev), rot_err=torch.from_numpy(re).to(dev))
+
+        # single gather of the per-problem results at the end (RCCL over xGMI when N > 1)
+        stats_local = torch.stack([res["pos_err"], res["rot_err"], res["iterations"].double(),
+                                   res["inner_total"].double(), res["n_accept"].double(),
+                                   res["stop"].double(), res["inner_executed"].double()], dim=1)
+        allstats = gd.gather_rows(stats_local, total, dst=0)
+        Y0_h = res["Y0"].cpu().numpy()
+
+        flags_local = res["flags"] if "flags" in res else None
+        lowrank_local = float((flags_local & 1).double().mean()) if flags_local is not None else 0.0
+        if rank != 0:
+            return None
+        st = allstats.cpu().numpy()
+        import hashlib
+        import torch.distributed as dist
+        gather = {"rows": int(st.shape[0]), "backend": dist.get_backend() if dist.is_initialized() else None,
+                  "sha256": hashlib.sha256(np.ascontiguousarray(st).tobytes()).hexdigest(),
+                  "note": "per-problem results [pos_err, rot_err, iterations, hv, accepted, stop, hv executed] "
+                          "of all ranks on rank 0: the ONE collective of the job (all_gather over RCCL)"}
+        pos, rot, its, inner, nacc, stop, execd = st.T
+        inner_local = float(res["inner_total"].double().sum())        # as the reference counts them
+        exec_local = float(res["inner_executed"].double().sum())      # Hessian products evaluated
+        outer_local = float(res["iterations"].double().sum())
+        acc_local = float(res["n_accept"].double().sum())
+        flops = algorithmic_flops(N, k, T, exec_local, outer_local, acc_local)   # executed products only
+        achieved_tf = flops / (kernel_ms * 1e-3) / 1e12
+        info = getattr(prob.template if anch is None else anch.template, "info", None)
+        flops_exec = executed_flops(N, k, T, info if anch is None else None, lowrank_local,
+                                    exec_local, outer_local, acc_local)
+        executed_tf = flops_exec / (kernel_ms * 1e-3) / 1e12
+        hbm_bytes = algorithmic_bytes(N, k, T) * B
+        value = total * steps / dt
+        base_idx = CONFIGS[cfg][3] if cfg else None
+        out = {
+            "metric": "IK solves/sec (batched random goals)",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{robot_name} N={N} k={k} terms={T}, {total} random goals "
+                                   f"({B} on rank 0; " +
+                                   (f"BASELINE configs[{base_idx}]" if base_idx is not None else "parity config")
+                                   + "), reference solver defaults (mingradnorm 5e-10, maxiter 3000)",
+                       "config": cfg, "robot": robot_name, "goals_total": total, "batch_per_gpu": B,
+                       "seed": args.seed,
+                       "step": ("goal poses (HBM) -> prepare kernel (goal distances, bound smoothing, "
+                                "MDS init) -> RTR solve kernel -> recover kernel (joint angles, FK "
+                                "pose error); no host work inside the timed region") if on_device else
+                               ("RTR solve kernel (workgroup per problem) on targets / Y_init resident in "
+                                "HBM; goal assembly and joint recovery run on the host outside the "
+                                "timed region (graphs beyond the device pipeline, N > 128)"),
+                       "parallelism": f"shard{world}", "batches_in_flight": streams},
+            "median_pos_err_m": float(np.median(pos)), "median_rot_err_rad": float(np.median(rot)),
+            "p90_pos_err_m": float(np.percentile(pos, 90)),
+            "success_rate": float(np.mean((pos < 0.01) & (rot < 0.01))),
+            "outer_iterations": {"median": float(np.median(its)), "max": float(its.max())},
+            "hv_products": {"median": float(np.median(inner)), "max": float(inner.max()),
+                            "total_per_gpu": inner_local, "executed_per_gpu": exec_local,
+                            "note": "median/max/total: tCG iterations as the reference counts them; "
+                                    "executed: Hessian products evaluated (a tCG solve after a rejected "
+                                    "step resumes from a checkpoint, bit-identical result); roofline "
+                                    "flops use executed"},
+            "frac_maxiter": float(np.mean(stop == 1)),
+            "roofline": {"bound": "fp64-valu", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
+                         "frac_executed": executed_tf / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel": (f"rtr_wave_kernel<{k},{prob.template.maxdeg}>" if N * k <= 64
+                                    else f"rtr_block_kernel<{k}>"), "kernel_ms": kernel_ms,
+                         "kernel_share_of_step": kernel_ms / (dt_local / steps * 1e3),
+                         "flops_per_launch": flops, "flops_executed_per_launch": flops_exec,
+                         "note": "fp64 vector ALU (the contract's \"mfma\" class: compute-bound, not HBM); "
+                                 "the solve is LDS/register resident and bound by the instruction issue "
+                                 "rate of one wavefront per problem (and, at this batch size, by the "
+                                 "slowest problem), not by HBM or MFMA (SURVEY 8(d), DESIGN 4.1); "
+                                 "peak = MI355X fp64 vector/matrix spec"
+                                 + ("" if N * k <= 64 else
+                                    "; workgroup-per-problem kernel: `achieved` / `frac` use the ALGORITHMIC "
+                                    "flop count of SURVEY 8(d) (12 k |E| per product); a rigid anchor clique "
+                                    "is evaluated in closed form with far fewer operations -- "
+                                    "`frac_executed` prices the flops the kernel actually executes "
+                                    "(bench.py: executed_flops, DESIGN 4.1)")},
+            "roofline_hbm": {"bound": "hbm", "achieved": hbm_bytes / (kernel_ms * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "bytes_per_launch": hbm_bytes},
+        }
+        out["gather"] = gather
+        if serving is not None:
+            out["serving"] = serving
+        traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        if robot_name == "ur10_table" and not intended:
+            traffic_file = os.path.join(REPO, "profiles", "r02_block_hbm_traffic.json")
+        if os.path.exists(traffic_file) and ((robot_name == "lwa4d" and B == 4096) or
+                                             (robot_name == "ur10_table" and B == 4096 and not intended)):   # profiled workloads only
+            try:
+                tj = json.load(open(traffic_file))
+                out["roofline"]["traffic"] = tj.get("bytes_per_launch")
+                out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(traffic_file)}: rocprofv3 --pmc "
+                                                     "passes of this command in a separate run "
+                                                     "(tools/profile.sh + tools/summarize_prof.py), not "
+                                                     "measured by the process that printed this line")
+            except Exception:
+                pass
+
+        if anch is not None:
+            Yh = res["x"].cpu().numpy()
+            clear = anch.clearance(Yh)
+            conv = (res["f"].cpu().numpy() < 1e-9)
+            out["intended"] = {
+                "formulation": "fixed anchors (base, goal nodes, obstacle centres are constants) + robot<->obstacle "
+                               "lower hinges; opt-in, NOT the reference's observable semantics (SURVEY 8(f)3)",
+                "free_nodes": N, "obstacles": int(len(anch.obstacles)),
+                "converged_frac": float(conv.mean()),
+                "collision_free_frac_of_converged": float((clear[conv] > -1e-4).mean()) if conv.any() else None,
+                "min_clearance_of_converged_m": float(clear[conv].min()) if conv.any() else None}
+            out["config"]["workload"] += " [--intended: fixed-anchor formulation, not the BASELINE semantics]"
+            out["roofline"]["kernel"] = "rtr_wave_kernel<3,9,anchored>"
+        if cpu and not args.no_cpu_baseline and world == 1 and prob.psi_L is not None and anch is None:   # rank 0, single-GPU runs
+            out["cpu_baseline"] = cpu_baseline(prob, T_goal, Y0_h, B, args)
+        return out
+
+
+def brief(o):
+    """The sub-record of a BASELINE config inside the default line's "configs" object."""
+    if o is None:
+        return None
+    if o.get("dry_solve"):
+        return {k: o[k] for k in ("rows", "rows_sha", "scaling", "ms_per_step")} | \
+            {"goals_total": o["config"]["goals_total"]}
+    r = o["roofline"]
+    return {"value": o["value"], "unit": "solves/s", "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+            "warmup": o["warmup"], "scaling": o["scaling"], "workload": o["config"]["workload"],
+            "goals_total": o["config"]["goals_total"], "batch_per_gpu": o["config"]["batch_per_gpu"],
+            "kernel": r["kernel"], "kernel_ms": r["kernel_ms"],
+            "roofline": {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
+                         "frac": r["frac"], "frac_executed": r["frac_executed"]},
+            "success_rate": o["success_rate"], "frac_maxiter": o["frac_maxiter"],
+            "median_pos_err_m": o["median_pos_err_m"], "median_rot_err_rad": o["median_rot_err_rad"],
+            "outer_iterations": o["outer_iterations"],
+            "hv_products_executed_per_gpu": o["hv_products"]["executed_per_gpu"]}
+
+
 def main():
     args = parse_args()
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not launched:
         sys.exit(self_launch(args))
 
-    import torch
-    from graphik_amd import distributed as gd
-
-    backend = args.backend or ("gloo" if args.dry_solve else None)
-    rank, local_rank, world = gd.init_process_group(backend=backend)
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); "
-                         f"run `python bench.py --gpus {args.gpus}` (self-launching) or "
-                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py "
-                         f"--gpus {args.gpus}`")
-    dry = args.dry_solve
-    if not dry:
-        assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
-    else:
-        dev = torch.device("cpu")
-
-    cfg, robot_name, total, scaling = workload(args, world)
-    robot, graph = build_graph(robot_name)
-    n = robot.n
-    lo, hi = gd.shard_range(total, rank, world)        # contiguous shard of the global goal stream
-    B = hi - lo
-    rs = np.random.RandomState(args.seed)
-    U = rs.rand(total, n)[lo:hi]
-    lb, ub = robot.limits_arrays()
-    T_goal = robot.fk_batch(lb + (ub - lb) * U)
-
-    if dry:
-        for _ in range(args.warmup):
-            st = dry_results(T_goal)
-        gd.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            st = dry_results(T_goal)
-        gd.barrier()
-        dt = gd.max_over_ranks(time.perf_counter() - t0, dev)
-        allstats = gd.gather_rows(torch.from_numpy(st), total, dst=0)
-        gd.shutdown()
-        if rank == 0:
-            a = allstats.numpy()
-            print(json.dumps({
-                "metric": "IK solves/sec (batched random goals)", "value": None, "unit": "solves/s",
-                "dry_solve": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": dt / args.steps * 1e3, "scaling": scaling,
-                "config": {"workload": f"{robot_name}, {total} goals over {world} rank(s)",
-                           "config": cfg, "robot": robot_name, "goals_total": total},
-                "rows": int(a.shape[0]), "checksum": float(a.sum()),
-                "rows_sha": __import__("hashlib").sha256(np.ascontiguousarray(a).tobytes()).hexdigest(),
-            }), flush=True)
-        return
-
-    from graphik_amd.solvers.riemannian_solver import AnchoredProblem, BatchProblem
-    anch = None
-    if args.intended:
-        if robot_name != "ur10_table":
-            raise SystemExit("--intended applies to --config c3 / --robot ur10_table")
-        anch = AnchoredProblem(graph, device=dev)
-        prob = anch.base
-        N, k = len(anch.free), 3
-        T = anch.template.T + len(anch.pin)              # terms the Hessian product sees
-    else:
-        prob = BatchProblem(graph, use_limits=True, device=dev)
-        N, k, T = graph.number_of_nodes(), graph.dim, prob.template.T
-    tpl = prob.template
-    on_device = prob.device_pipeline
-    Tg_dev = torch.from_numpy(T_goal).to(dev)        # inputs resident in HBM
-    if not on_device:
-        tg_h, Y0_h0 = prob.prepare(T_goal)
-        tg_dev, Y0_dev = torch.from_numpy(tg_h).to(dev), torch.from_numpy(Y0_h0).to(dev)
-    torch.cuda.synchronize(dev)
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-
-    anch_ms = []
-
-    def step(i=None):
-        """goal poses -> joint angles + pose errors, entirely on the device: prepare
-        (from_pose, bound smoothing, MDS init) -> RTR solve -> recover (joint_variables, FK)."""
-        if anch is not None:        # fixed-anchor pipeline: one C call (prepare, fit, solve, gather, recover)
-            res = anch.template.anchored_ik(tpl, Tg_dev)
-            if i is not None:
-                anch_ms.append(anch.template)
-            res.update(Y0=res["x"])
-            return res
-        targets, Y0 = tpl.prepare(Tg_dev) if on_device else (tg_dev, Y0_dev)
-        if i is not None:
-            ev0[i].record()      # all kernels are launched on torch's current stream
-        res = tpl.solve(Y0, targets)
-        if i is not None:
-            ev1[i].record()
-        if on_device:
-            q, pe, re = tpl.recover(res["x"], Tg_dev)
-            res.update(q=q, pos_err=pe, rot_err=re)
-        res.update(Y0=Y0)
-        return res
-
-    for _ in range(args.warmup):
-        res = step()
-    torch.cuda.synchronize(dev)
-    gd.barrier()
-    torch.cuda.synchronize(dev)
-    streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else None
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if streams is None:
-            res = step(i)
-        else:                      # every step is the same full batch; S of them are in flight
-            with torch.cuda.stream(streams[i % args.streams]):
-                res = step(i)
-    torch.cuda.synchronize(dev)
-    gd.barrier()
-    dt_local = time.perf_counter() - t0
-    dt = gd.max_over_ranks(dt_local, dev)
-    if anch is not None:        # (events recorded inside the C call around the solve kernel: last step)
-        kernel_ms = float(anch.template.lib.gik_anchored_last_solve_ms(anch.template._h))
-    else:
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
-
-    # Serving configuration, reported separately (NOT `value`): the same batches, S in flight on
-    # separate HIP streams, so the straggler tail of one batch overlaps with the bulk of the next.
-    serving = None
-    S = args.serving_streams
-    if S > 1 and args.streams == 1 and dt / args.steps < 0.5:   # (skipped for multi-second batches)
-        nb = 4 * S
-        sv_streams = [torch.cuda.Stream(dev) for _ in range(S)]
-        for s_ in sv_streams:                        # warm the per-stream allocations
-            with torch.cuda.stream(s_):
-                step()
-        torch.cuda.synchronize(dev)
-        gd.barrier()
-        ts = time.perf_counter()
-        for i in range(nb):
-            with torch.cuda.stream(sv_streams[i % S]):
-                step()
-        torch.cuda.synchronize(dev)
-        gd.barrier()
-        dts = gd.max_over_ranks(time.perf_counter() - ts, dev)
-        serving = {"value": total * nb / dts, "unit": "solves/s", "batches_in_flight": S,
-                   "batches": nb, "ms_per_batch": dts / nb * 1e3,
-                   "note": "same workload and kernels as `value`; S batches in flight on separate HIP "
-                           "streams (a serving configuration: independent requests overlap, the "
-                           "straggler tail of one batch runs beside the bulk of the next)"}
-
-    if not on_device:   # host post-processing, after the timed region
-        qh = prob.joint_variables(res["x"].cpu().numpy(), T_goal)
-        pe, re = prob.pose_errors(qh, T_goal)
-        res.update(pos_err=torch.from_numpy(pe).to(dev), rot_err=torch.from_numpy(re).to(dev))
-
-    # single gather of the per-problem results at the end (RCCL over xGMI when N > 1)
-    stats_local = torch.stack([res["pos_err"], res["rot_err"], res["iterations"].double(),
-                               res["inner_total"].double(), res["n_accept"].double(),
-                               res["stop"].double(), res["inner_executed"].double()], dim=1)
-    allstats = gd.gather_rows(stats_local, total, dst=0)
-    Y0_h = res["Y0"].cpu().numpy()
-
-    if rank != 0:
-        gd.shutdown()
-        return
-    st = allstats.cpu().numpy()
-    pos, rot, its, inner, nacc, stop, execd = st.T
-    inner_local = float(res["inner_total"].double().sum())        # as the reference counts them
-    exec_local = float(res["inner_executed"].double().sum())      # Hessian products evaluated
-    outer_local = float(res["iterations"].double().sum())
-    acc_local = float(res["n_accept"].double().sum())
-    flops = algorithmic_flops(N, k, T, exec_local, outer_local, acc_local)   # executed work only
-    achieved_tf = flops / (kernel_ms * 1e-3) / 1e12
-    hbm_bytes = algorithmic_bytes(N, k, T) * B
-    value = total * args.steps / dt
-    base_idx = CONFIGS[cfg][3] if cfg else None
-    out = {
-        "metric": "IK solves/sec (batched random goals)",
-        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{robot_name} N={N} k={k} terms={T}, {total} random goals "
-                               f"({B} on rank 0; " +
-                               (f"BASELINE configs[{base_idx}]" if base_idx is not None else "parity config")
-                               + "), reference solver defaults (mingradnorm 5e-10, maxiter 3000)",
-                   "config": cfg, "robot": robot_name, "goals_total": total, "batch_per_gpu": B,
-                   "seed": args.seed,
-                   "step": ("goal poses (HBM) -> prepare kernel (goal distances, bound smoothing, "
-                            "MDS init) -> RTR solve kernel -> recover kernel (joint angles, FK "
-                            "pose error); no host work inside the timed region") if on_device else
-                           ("RTR solve kernel (workgroup per problem) on targets / Y_init resident in "
-                            "HBM; goal assembly and joint recovery run on the host outside the "
-                            "timed region (graphs beyond the device pipeline, N > 128)"),
-                   "parallelism": f"shard{world}", "batches_in_flight": args.streams},
-        "median_pos_err_m": float(np.median(pos)), "median_rot_err_rad": float(np.median(rot)),
-        "p90_pos_err_m": float(np.percentile(pos, 90)),
-        "success_rate": float(np.mean((pos < 0.01) & (rot < 0.01))),
-        "outer_iterations": {"median": float(np.median(its)), "max": float(its.max())},
-        "hv_products": {"median": float(np.median(inner)), "max": float(inner.max()),
-                        "total_per_gpu": inner_local, "executed_per_gpu": exec_local,
-                        "note": "median/max/total: tCG iterations as the reference counts them; "
-                                "executed: Hessian products evaluated (a tCG solve after a rejected "
-                                "step resumes from a checkpoint, bit-identical result); roofline "
-                                "flops use executed"},
-        "frac_maxiter": float(np.mean(stop == 1)),
-        "roofline": {"bound": "fp64-valu", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": None,
-                     "kernel": (f"rtr_wave_kernel<{k},{prob.template.maxdeg}>" if N * k <= 64
-                                else f"rtr_block_kernel<{k}>"), "kernel_ms": kernel_ms,
-                     "kernel_share_of_step": kernel_ms / (dt_local / args.steps * 1e3),
-                     "flops_per_launch": flops,
-                     "note": "fp64 vector ALU (the contract's \"mfma\" class: compute-bound, not HBM); "
-                             "the solve is LDS/register resident and bound by the instruction issue "
-                             "rate of one wavefront per problem (and, at this batch size, by the "
-                             "slowest problem), not by HBM or MFMA (SURVEY 8(d), DESIGN 4.1); "
-                             "peak = MI355X fp64 vector/matrix spec"
-                             + ("" if N * k <= 64 else
-                                "; workgroup-per-problem kernel: `achieved` is the ALGORITHMIC flop count "
-                                "of SURVEY 8(d) (12 k |E| per product) -- a rigid anchor clique is "
-                                "evaluated in closed form with about a tenth of those operations "
-                                "(DESIGN 4.1)")},
-        "roofline_hbm": {"bound": "hbm", "achieved": hbm_bytes / (kernel_ms * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "bytes_per_launch": hbm_bytes},
-    }
-    if serving is not None:
-        out["serving"] = serving
-    traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json")
-    if robot_name == "ur10_table" and not args.intended:
-        traffic_file = os.path.join(REPO, "profiles", "r02_block_hbm_traffic.json")
-    if os.path.exists(traffic_file) and ((robot_name == "lwa4d" and B == 4096) or
-                                         (robot_name == "ur10_table" and B == 4096 and not args.intended)):   # profiled workloads only
-        try:
-            tj = json.load(open(traffic_file))
-            out["roofline"]["traffic"] = tj.get("bytes_per_launch")
-            out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(traffic_file)}: rocprofv3 --pmc "
-                                                 "passes of this command in a separate run "
-                                                 "(tools/profile.sh + tools/summarize_prof.py), not "
-                                                 "measured by the process that printed this line")
-        except Exception:
-            pass
-
-    if anch is not None:
-        Yh = res["x"].cpu().numpy()
-        clear = anch.clearance(Yh)
-        conv = (res["f"].cpu().numpy() < 1e-9)
-        out["intended"] = {
-            "formulation": "fixed anchors (base, goal nodes, obstacle centres are constants) + robot<->obstacle "
-                           "lower hinges; opt-in, NOT the reference's observable semantics (SURVEY 8(f)3)",
-            "free_nodes": N, "obstacles": int(len(anch.obstacles)),
-            "converged_frac": float(conv.mean()),
-            "collision_free_frac_of_converged": float((clear[conv] > -1e-4).mean()) if conv.any() else None,
-            "min_clearance_of_converged_m": float(clear[conv].min()) if conv.any() else None}
-        out["config"]["workload"] += " [--intended: fixed-anchor formulation, not the BASELINE semantics]"
-        out["roofline"]["kernel"] = "rtr_wave_kernel<3,9,anchored>"
-    if not args.no_cpu_baseline and world == 1 and prob.psi_L is not None and anch is None:   # rank 0, single-GPU runs
-        out["cpu_baseline"] = cpu_baseline(prob, T_goal, Y0_h, B, args)
-    gd.shutdown()
-    print(json.dumps(out), flush=True)
+    b = Bench(args)
+    cfg, robot_name, total, scaling = workload(args, b.world)
+    out = b.measure(cfg, robot_name, total, scaling, args.steps, args.warmup,
+                    serving_streams=args.serving_streams, cpu=True, streams=args.streams,
+                    intended=args.intended)
+    # The default invocation (`python bench.py [--gpus N]`, what the driver runs) also times the other
+    # BASELINE workloads after the headline, a few steps each, and reports them under "configs" in
+    # the same line: c3 (UR10 + table, 4096 goals per GPU), c4 (KUKA, 65536 goals sharded over the
+    # GPUs: strong scaling; on one GPU also its 8192-goal per-GPU share of an 8-GPU run) and c5
+    # (planar-10, 65536 sharded).  --headline-only skips them.
+    default_run = (args.config is None and args.robot is None and not args.batch and not args.intended
+                   and args.streams == 1 and not args.headline_only)
+    if default_run:
+        extra = {}
+        plan = [("c3", "ur10_table", 4096 * b.world, "weak", 2, 1),
+                ("c4", "kuka", 65536, "strong", 3, 1),
+                ("c5", "planar10", 65536, "strong", 5, 1)]
+        if b.world == 1:
+            plan.insert(2, ("c4_share_of_8", "kuka", 8192, "strong", 5, 1))
+        for name, rb, tot, sc, st, wu in plan:
+            o = b.measure(name[:2], rb, tot, sc, st, wu)
+            if b.rank == 0:
+                extra[name] = brief(o)
+        if b.rank == 0:
+            out["configs"] = extra
+    b.gd.shutdown()
+    if b.rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

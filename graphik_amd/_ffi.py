@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GIK_LIB_PATH") or os.path.join(_HERE, "lib", "libgraphik_amd.so")
 
 TERM_EQ, TERM_LOWER, TERM_UPPER = 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class TemplateDesc(C.Structure):
@@ -29,8 +29,19 @@ class TemplateDesc(C.Structure):
         ("planar_proj_exact", C.c_int32), ("force_block_path", C.c_int32),
         ("waves_per_cu", C.c_int32), ("slice_outer_its", C.c_int32), ("debug_flags", C.c_int32),
         ("solver", C.c_int32), ("cg_minstepsize", C.c_double), ("cg_orth_value", C.c_double),
-        ("cg_beta_type", C.c_int32), ("reserved1", C.c_int32),
+        ("cg_beta_type", C.c_int32), ("clique_closed_form", C.c_int32),
     ]
+
+
+CLIQUE_AUTO, CLIQUE_OFF, CLIQUE_DENSE = 0, 1, 2
+
+
+class TemplateInfo(C.Structure):
+    _fields_ = [("is_block", C.c_int32), ("max_terms_per_node", C.c_int32), ("n_clique", C.c_int32),
+                ("n_slot_terms", C.c_int32), ("slots_per_thread", C.c_int32), ("waves_per_cu", C.c_int32),
+                ("n_cu", C.c_int32), ("lds_bytes", C.c_int32), ("clique_closed_form", C.c_int32),
+                ("anchored", C.c_int32), ("has_pipeline", C.c_int32), ("prepare_is_block", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
 
 
 SOLVER_TRUST_REGIONS, SOLVER_CONJUGATE_GRADIENT = 0, 1
@@ -106,6 +117,7 @@ SYMBOLS = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gik_anchored_last_solve_ms": (C.c_double, [C.c_void_p]),
     "gik_template_destroy": (None, [C.c_void_p]),
+    "gik_template_get_info": (C.c_int, [C.c_void_p, C.POINTER(TemplateInfo)]),
     "gik_cost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gik_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gik_cost_and_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
@@ -139,12 +151,20 @@ def lib():
     if _lib is None:
         if "GIK_LIB_PATH" not in os.environ:
             # never run against a binary that is older than its sources: rebuild when the toolchain
-            # is here (17 s), refuse otherwise
+            # is here (one process builds under a file lock, the others wait), refuse otherwise.  A
+            # prebuilt library whose .digest stamp was lost in packaging cannot be checked: with no
+            # toolchain it is used as it is, with a warning.
             from . import build as _build
             if os.path.exists(LIB_PATH) and _build._stale(LIB_PATH):
-                import shutil
-                if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
-                    _build.build()
+                if _build.have_toolchain():
+                    try:
+                        _build.build()
+                    except (OSError, RuntimeError, __import__("subprocess").CalledProcessError) as e:
+                        raise GikError(f"rebuilding {LIB_PATH} failed: {e}") from e
+                elif not os.path.exists(LIB_PATH + ".digest"):
+                    import warnings
+                    warnings.warn(f"{LIB_PATH}.digest is missing and there is no hipcc: cannot check "
+                                  "that the library matches the sources in this tree")
                 else:
                     raise GikError(f"{LIB_PATH} was built from other sources than the ones in this tree "
                                    "and there is no hipcc to rebuild it")

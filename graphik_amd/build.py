@@ -45,7 +45,15 @@ def _stale(lib, extra=()):
     return open(stamp).read().strip() != source_digest(extra)
 
 
-def _compile(lib, extra, verbose):
+def have_toolchain():
+    return bool(shutil.which("hipcc")) or os.path.exists("/opt/rocm/bin/hipcc")
+
+
+def _compile(lib, extra, verbose, force=False):
+    """Compile to a temporary file and os.replace() it into place, under an exclusive file lock:
+    several ranks (bench.py --gpus N, the gloo tests) may find the library stale at the same time;
+    one of them builds, the others wait for the lock, see a current digest and return."""
+    import fcntl
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         # a machine without the toolchain (the GPU box ships the prebuilt library) cannot rebuild
@@ -53,13 +61,27 @@ def _compile(lib, extra, verbose):
             return lib
         raise RuntimeError("hipcc not found and " + lib + " is missing")
     os.makedirs(os.path.dirname(lib), exist_ok=True)
-    cmd = [hipcc] + FLAGS + list(extra) + ["-I" + os.path.join(REPO, "include"), "-I" + SRC]
-    cmd += [os.path.join(SRC, s) for s in SOURCES] + ["-o", lib]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    with open(lib + ".digest", "w") as f:
-        f.write(source_digest(extra) + "\n")
+    with open(lib + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale(lib, extra):      # another process built it meanwhile
+                return lib
+            tmp = f"{lib}.tmp.{os.getpid()}"
+            cmd = [hipcc] + FLAGS + list(extra) + ["-I" + os.path.join(REPO, "include"), "-I" + SRC]
+            cmd += [os.path.join(SRC, s) for s in SOURCES] + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, lib)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+            with open(lib + ".digest.tmp", "w") as f:
+                f.write(source_digest(extra) + "\n")
+            os.replace(lib + ".digest.tmp", lib + ".digest")
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return lib
 
 
@@ -68,14 +90,14 @@ def build(force=False, verbose=False):
     any file under csrc/ or include/ (or the flags) differs from what the library was built from."""
     if not force and not _stale(LIB):
         return LIB
-    return _compile(LIB, (), verbose)
+    return _compile(LIB, (), verbose, force)
 
 
 def build_dev(force=False, verbose=False):
     extra = ("-DGIK_DEV",)
     if not force and not _stale(DEV_LIB, extra):
         return DEV_LIB
-    return _compile(DEV_LIB, extra, verbose)
+    return _compile(DEV_LIB, extra, verbose, force)
 
 
 if __name__ == "__main__":

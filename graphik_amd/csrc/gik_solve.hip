@@ -731,8 +731,20 @@ struct gik_template {
   gik::Params p;
   const gik::Variant *variant;
   uint32_t *d_slot_meta;
-  unsigned int *d_counters;  // ring of work-queue heads, one per in-flight solve call
-  std::atomic<unsigned> next_counter;
+  // Ring of work-queue heads, one per in-flight solve call.  A slot is handed out again only
+  // behind the event recorded after the launch that used it last (the new call's stream waits for
+  // it), so a wrap of the ring can never reset the counter of a kernel that is still running --
+  // whatever the number of calls in flight.
+  unsigned int *d_counters;
+  struct CounterSlot {
+    hipEvent_t done = nullptr;
+    bool pending = false;
+  };
+  std::vector<CounterSlot> counter_slot;   // [kCounterRing]
+  unsigned next_counter = 0;
+  std::mutex call_mutex;    // counter ring + time-slicing pool: held from slot hand-out to event record
+  std::mutex ev_mutex;      // ev_solve0 / ev_solve1 (anchored templates)
+  int clique_mode = 0;      // gik_template_desc::clique_closed_form as resolved at creation
   // time-slicing workspaces (re-queue ring + paused state), a small pool handed out round-robin;
   // a launch that gets a slot still in use by an earlier launch waits for it on its stream
   struct SliceWs {
@@ -743,7 +755,6 @@ struct gik_template {
   };
   static constexpr int kSlicePool = 8;
   SliceWs slice_ws[kSlicePool];
-  std::mutex slice_mutex;
   unsigned next_slice = 0;
   int device;
   int n_cu;
@@ -772,6 +783,7 @@ struct gik_template {
   int sweeps;
 };
 static constexpr int kCounterRing = 256;
+static int g_counter_ring = kCounterRing;   // GIK_COUNTER_RING (tests: a tiny ring must still be safe)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a launch: several
 // templates share a kernel, so the allowance is only ever raised (a later, smaller template must
@@ -838,7 +850,7 @@ void gik_default_params(gik_template_desc *d) {
   d->cg_minstepsize = 1e-10;    // riemannian_solver.py:56
   d->cg_orth_value = 10e10;     // :57
   d->cg_beta_type = 3;          // :58  BetaTypes[3] = HagerZhang
-  d->reserved1 = 0;
+  d->clique_closed_form = GIK_CLIQUE_AUTO;
 }
 
 void gik_default_cg_params(gik_template_desc *d) {
@@ -877,6 +889,9 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   if (d->solver != GIK_SOLVER_TRUST_REGIONS && d->solver != GIK_SOLVER_CONJUGATE_GRADIENT)
     return fail("solver must be GIK_SOLVER_TRUST_REGIONS or GIK_SOLVER_CONJUGATE_GRADIENT");
   if (d->cg_beta_type < 0 || d->cg_beta_type > 3) return fail("cg_beta_type must be 0..3");
+  if (d->clique_closed_form < GIK_CLIQUE_AUTO || d->clique_closed_form > GIK_CLIQUE_DENSE)
+    return fail("clique_closed_form must be GIK_CLIQUE_AUTO, _OFF or _DENSE");
+  if (const char *e = getenv("GIK_COUNTER_RING")) g_counter_ring = std::min(kCounterRing, std::max(1, atoi(e)));
   bool is_block = d->N * d->k > WAVE || d->N > 32 || d->force_block_path != 0;
   if (d->N < 2 || d->N > BLOCK_MAXN) return fail("N must be in [2, 128]");
   if (d->n_terms < 1 || d->n_terms > 65535) return fail("n_terms out of range");
@@ -931,7 +946,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     }
     std::vector<char> in_clq(N, 0);
     const int clique_min = (dbg_eff & 64) ? 4 : 16;
-    if (d->k == 3 && !(dbg_eff & 128)) {
+    if (d->k == 3 && !(dbg_eff & 128) && d->clique_closed_form != GIK_CLIQUE_OFF) {
       for (int i = 0; i < N; ++i) order[i] = i;
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return deg[a] > deg[b]; });
       std::vector<int> A;
@@ -1083,6 +1098,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   t->d_slot_meta = nullptr;
   t->d_counters = nullptr;
   t->next_counter = 0;
+  t->counter_slot.resize(kCounterRing);
   t->has_pipe = false;
   t->smem_bytes = is_block ? (d->k == 3 ? BlockCtx<3>::lds_bytes(Tc, SL) : BlockCtx<2>::lds_bytes(Tc, SL))
                            : (ad ? var->lds_anch(T) : var->lds(T));
@@ -1168,6 +1184,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     t->n_anchor = ad->n_anchor;
     t->axis_length = ad->axis_length;
     t->anchored = true;
+    if (hipEventCreate(&t->ev_solve0) != hipSuccess || hipEventCreate(&t->ev_solve1) != hipSuccess) ok = false;
     if (!ok) {
       gik_template_destroy(t);
       return fail("anchored templates: bad pinned term (node / anchor / kind out of range, or more than 8 per node) "
@@ -1182,7 +1199,8 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     t->bt.wave_sl = upload(t, wave_sl.data(), wave_sl.size(), ok);
     t->bt.Tc = Tc;
     t->bt.n_clq = n_clq;
-    t->bt.clq_euclid = (n_clq && !(dbg_eff & 256)) ? 1 : 0;   // 256: always the dense D w product
+    t->bt.clq_euclid = (n_clq && !(dbg_eff & 256) && d->clique_closed_form != GIK_CLIQUE_DENSE) ? 1 : 0;   // 256: always the dense D w product
+    t->clique_mode = !n_clq ? GIK_CLIQUE_OFF : (t->bt.clq_euclid ? GIK_CLIQUE_AUTO : GIK_CLIQUE_DENSE);
     if (!ok) {
       gik_template_destroy(t);
       return fail("device upload of the workgroup-path tables failed");
@@ -1210,6 +1228,8 @@ void gik_template_destroy(gik_template *t) {
   if (t->ev_solve0) (void)hipEventDestroy(t->ev_solve0);
   if (t->ev_solve1) (void)hipEventDestroy(t->ev_solve1);
   if (t->prep_done) (void)hipEventDestroy(t->prep_done);
+  for (auto &c : t->counter_slot)
+    if (c.done) (void)hipEventDestroy(c.done);
   for (auto &w : t->slice_ws) {
     if (w.base) (void)hipFree(w.base);
     if (w.done) (void)hipEventDestroy(w.done);
@@ -1448,15 +1468,17 @@ int gik_anchored_ik_batch(const gik_template *anch, const gik_template *base, co
   // ... mapped onto the world frame by its anchors; free rows = anchored start point
   hipLaunchKernelGGL(anch_init_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, g);
   HIP_OK(hipGetLastError());
-  gik_template *ma = const_cast<gik_template *>(anch);   // (timing events: diagnostics only)
-  if (!ma->ev_solve0) {
-    (void)hipEventCreate(&ma->ev_solve0);
-    (void)hipEventCreate(&ma->ev_solve1);
+  // timing events around the solve (diagnostics only; created with the handle).  The pair is
+  // recorded under a lock so that gik_anchored_last_solve_ms never reads a half-recorded pair;
+  // with concurrent callers it reports whichever call recorded last.
+  gik_template *ma = const_cast<gik_template *>(anch);
+  {
+    std::lock_guard<std::mutex> lock(ma->ev_mutex);
+    (void)hipEventRecord(ma->ev_solve0, (hipStream_t)stream);
+    rc = gik_solve_batch(anch, Y_free, goal, B, Y_free, d_stats, nullptr, stream);
+    if (rc) return rc;
+    (void)hipEventRecord(ma->ev_solve1, (hipStream_t)stream);
   }
-  (void)hipEventRecord(ma->ev_solve0, (hipStream_t)stream);
-  rc = gik_solve_batch(anch, Y_free, goal, B, Y_free, d_stats, nullptr, stream);
-  if (rc) return rc;
-  (void)hipEventRecord(ma->ev_solve1, (hipStream_t)stream);
   hipLaunchKernelGGL(anch_gather_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, g);
   HIP_OK(hipGetLastError());
   return gik_recover_batch(base, d_Y_full, d_T_goal, B, d_q, d_pos_err, d_rot_err, stream);
@@ -1465,6 +1487,7 @@ int gik_anchored_ik_batch(const gik_template *anch, const gik_template *base, co
 double gik_anchored_last_solve_ms(const gik_template *anch) {
   if (!anch || !anch->ev_solve0) return -1.0;
   float ms = -1.0f;
+  std::lock_guard<std::mutex> lock(const_cast<gik_template *>(anch)->ev_mutex);
   if (hipEventSynchronize(anch->ev_solve1) != hipSuccess ||
       hipEventElapsedTime(&ms, anch->ev_solve0, anch->ev_solve1) != hipSuccess)
     return -1.0;
@@ -1585,8 +1608,16 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     g_dbg_buf = buf;
   }
 #endif
-  gik_template *mt = const_cast<gik_template *>(t);  // the counter ring is the only mutable part
-  a.work_counter = t->d_counters + (mt->next_counter.fetch_add(1) % kCounterRing);
+  // The handle's mutable parts: the ring of work-queue heads and the time-slicing workspaces.  Both
+  // are handed out under call_mutex, held until the event that guards their reuse is recorded, so
+  // concurrent calls on one handle (any number of host threads and streams) are safe.
+  gik_template *mt = const_cast<gik_template *>(t);
+  std::lock_guard<std::mutex> call_lock(mt->call_mutex);
+  gik_template::CounterSlot &cs = mt->counter_slot[mt->next_counter++ % (unsigned)g_counter_ring];
+  a.work_counter = t->d_counters + (&cs - mt->counter_slot.data());
+  if (!cs.done && hipEventCreateWithFlags(&cs.done, hipEventDisableTiming) != hipSuccess)
+    return fail("hipEventCreate failed");
+  if (cs.pending) HIP_OK(hipStreamWaitEvent((hipStream_t)stream, cs.done, 0));   // ring wrapped: previous user first
   HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned int), (hipStream_t)stream));
   // Persistent waves per CU: as many as fit (two per SIMD at 249 VGPRs).  Two waves share a SIMD's
   // fp64 pipe and each runs 20-50 % slower than alone, which used to cost small batches -- whose
@@ -1618,7 +1649,6 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     const size_t cap = (size_t)B * (size_t)(t->p.maxiter / slice + 1);
     const size_t off_seq = 16, off_ids = off_seq + cap * 4, off_state = (off_ids + cap * 4 + 15) & ~(size_t)15;
     const size_t bytes = off_state + (size_t)B * sizeof(SliceState);
-    std::lock_guard<std::mutex> lock(mt->slice_mutex);
     sw = &mt->slice_ws[mt->next_slice++ % gik_template::kSlicePool];
     if (!sw->done && hipEventCreateWithFlags(&sw->done, hipEventDisableTiming) != hipSuccess)
       return fail("hipEventCreate failed");
@@ -1653,11 +1683,30 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
                        dim3(grid), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
   }
   HIP_OK(hipGetLastError());
+  HIP_OK(hipEventRecord(cs.done, (hipStream_t)stream));
+  cs.pending = true;
   if (sw) {
-    std::lock_guard<std::mutex> lock(mt->slice_mutex);
     HIP_OK(hipEventRecord(sw->done, (hipStream_t)stream));
     sw->pending = true;
   }
+  return 0;
+}
+
+int gik_template_get_info(const gik_template *t, gik_template_info *info) {
+  if (!t || !info) return gik::fail("null argument");
+  std::memset(info, 0, sizeof(*info));
+  info->is_block = t->is_block ? 1 : 0;
+  info->max_terms_per_node = t->is_block ? 0 : t->variant->maxdeg;
+  info->n_clique = t->bt.n_clq;
+  info->n_slot_terms = t->is_block ? t->bt.Tc : t->T;
+  info->slots_per_thread = t->SL;
+  info->waves_per_cu = t->waves_per_cu;
+  info->n_cu = t->n_cu;
+  info->lds_bytes = (int32_t)t->smem_bytes;
+  info->clique_closed_form = t->clique_mode;
+  info->anchored = t->anchored ? 1 : 0;
+  info->has_pipeline = t->has_pipe ? 1 : 0;
+  info->prepare_is_block = t->prep_block ? 1 : 0;
   return 0;
 }
 

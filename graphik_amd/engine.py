@@ -109,13 +109,15 @@ class Template:
             key = alias.get(key, key)
             if not hasattr(d, key):
                 raise KeyError(f"unknown solver parameter {key!r}")
-            setattr(d, key, int(val) if key in ("maxiter", "cg_beta_type") else val)
+            if key == "clique_closed_form" and isinstance(val, str):
+                val = {"auto": _ffi.CLIQUE_AUTO, "off": _ffi.CLIQUE_OFF, "dense": _ffi.CLIQUE_DENSE}[val]
+            setattr(d, key, int(val) if key in ("maxiter", "cg_beta_type", "clique_closed_form") else val)
         self.params = {f: getattr(d, f) for f in ("mingradnorm", "maxiter", "maxinner", "mininner",
                                                    "theta", "kappa", "rho_prime",
                                                    "rho_regularization", "planar_proj_exact",
                                                    "force_block_path", "waves_per_cu",
                                                    "slice_outer_its", "debug_flags", "cg_minstepsize",
-                                                   "cg_orth_value", "cg_beta_type")}
+                                                   "cg_orth_value", "cg_beta_type", "clique_closed_form")}
         self.params["solver"] = self.solver
         h = C.c_void_p()
         self.anchored = anchored is not None
@@ -147,6 +149,9 @@ class Template:
                 self.n_goal_anchor, self.full_N = ad.n_goal_anchor, ad.full_N
                 _ffi.check(self.lib.gik_template_create_anchored(C.byref(d), C.byref(ad), C.byref(h)))
         self._h = h
+        info = _ffi.TemplateInfo()
+        _ffi.check(self.lib.gik_template_get_info(self._h, C.byref(info)))
+        self.info = {f: getattr(info, f) for f, _ in _ffi.TemplateInfo._fields_ if f != "reserved"}
         deg = np.bincount(np.concatenate([self.term_i, self.term_j]), minlength=self.N).max()
         self.maxdeg = next((m for m in ((9, 10, 20) if self.k == 3 else (6, 16, 31)) if m >= deg), int(deg))
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GIK_ABI_VERSION 3
+#define GIK_ABI_VERSION 4
 
 /* Residual-term kinds: one "term" per (index pair, kind) exactly as the loops of
  * costs.py:80-207 visit them: equality (omega != 0), lower hinge (psi_L != 0), upper hinge
@@ -76,7 +76,8 @@ typedef struct {
   int32_t debug_flags;       /* developer flags (gik_solve.hip: SolveArgs::dbg); 16 = rerun tCG
                                 after a rejected step instead of resuming from the checkpoint;
                                 workgroup path: 64 = closed form for rigid cliques from 4 nodes
-                                up (default: 16 nodes), 128 = no closed form (direct sums)     */
+                                up (default: 16 nodes); 128 / 256 = older spellings of
+                                clique_closed_form = GIK_CLIQUE_OFF / GIK_CLIQUE_DENSE          */
   /* which of the reference's two solvers gik_solve_batch runs (riemannian_solver.py:40-65):
    * GIK_SOLVER_TRUST_REGIONS (default) or GIK_SOLVER_CONJUGATE_GRADIENT = pymanopt 0.2.5
    * ConjugateGradient + LineSearchAdaptive as configured at :51-59.  The CG defaults of
@@ -86,12 +87,36 @@ typedef struct {
   double cg_orth_value;      /* 10e10                                                         */
   int32_t cg_beta_type;      /* 0 FletcherReeves, 1 PolakRibiere, 2 HestenesStiefel, 3 HagerZhang
                                 (the reference passes BetaTypes[3])                           */
-  int32_t reserved1;
+  /* Workgroup-per-problem path only (N*k > 64): a rigid clique -- >= 16 nodes every pair of which
+   * is tied by an equality term, i.e. the anchors of a scene with obstacles (graph_base.py:182-199)
+   * -- is taken out of the per-term loops and its share of lhess (costs.py:175-207) is evaluated
+   * in closed form from 18 moments (+ 9 when the clique's targets are distances of points).  Same
+   * function, different SUMMATION ORDER: Hessian products agree with the reference's edge loop to
+   * round-off (<= 2e-15 relative), not bit for bit, so trust-region iteration counts near an
+   * accept / reject threshold can differ from a run with GIK_CLIQUE_OFF (which sums the terms in
+   * the reference's order).  gik_stats.flags bit 0 and gik_template_get_info report what ran.   */
+  int32_t clique_closed_form; /* GIK_CLIQUE_AUTO (default) | GIK_CLIQUE_OFF | GIK_CLIQUE_DENSE     */
 } gik_template_desc;
 
 enum { GIK_SOLVER_TRUST_REGIONS = 0, GIK_SOLVER_CONJUGATE_GRADIENT = 1 };
+enum {
+  GIK_CLIQUE_AUTO = 0,  /* closed form; (D w) by moments when the targets are Euclidean (checked per problem) */
+  GIK_CLIQUE_OFF = 1,   /* every term in the per-term loops, the reference's summation order               */
+  GIK_CLIQUE_DENSE = 2  /* closed form with the dense (D w) product always                                 */
+};
 
-typedef struct gik_template gik_template; /* opaque handle, immutable after creation */
+/* Opaque handle.  The problem description in it is immutable after gik_template_create /
+ * gik_pipeline_attach; what a batch call mutates is bookkeeping only, guarded inside the library:
+ *   - a ring of work-queue counters and a pool of time-slicing workspaces, handed out per call
+ *     under a mutex; a slot is reused only behind the event recorded after its previous launch, so
+ *     any number of calls may be in flight on any number of streams and host threads;
+ *   - the workgroup-per-goal prepare kernel's scratch slab (N > 32): launches on different streams
+ *     are chained by an event (they serialise; results are unaffected);
+ *   - anchored templates: the event pair read by gik_anchored_last_solve_ms (diagnostic; with
+ *     concurrent callers it reports whichever call recorded last).
+ * Results never depend on any of it.  Destroying a handle while calls on it are in flight is
+ * undefined; synchronise first.                                                                  */
+typedef struct gik_template gik_template;
 
 /* Per-problem solver statistics (final_values of the reference's optlog + counters). */
 typedef struct {
@@ -140,6 +165,24 @@ void gik_default_cg_params(gik_template_desc *desc);
 
 int gik_template_create(const gik_template_desc *desc, gik_template **out);
 void gik_template_destroy(gik_template *t);
+
+/* What gik_template_create decided (informational; e.g. bench.py's executed-flop count).        */
+typedef struct {
+  int32_t is_block;            /* 1: workgroup-per-problem kernels (N*k > 64 or forced)             */
+  int32_t max_terms_per_node;  /* compiled slot count of the wavefront kernel variant (0 on the block path) */
+  int32_t n_clique;            /* nodes of the rigid clique handled in closed form (0 = none)       */
+  int32_t n_slot_terms;        /* terms left in the per-term loops (= T without a clique)           */
+  int32_t slots_per_thread;    /* block path: padded per-thread slot count                          */
+  int32_t waves_per_cu;        /* resident solve wavefronts (workgroups) per CU                     */
+  int32_t n_cu;
+  int32_t lds_bytes;           /* dynamic LDS per wavefront / workgroup of the solve kernel         */
+  int32_t clique_closed_form;  /* GIK_CLIQUE_* in effect                                            */
+  int32_t anchored;
+  int32_t has_pipeline;
+  int32_t prepare_is_block;    /* workgroup-per-goal prepare kernel                                 */
+  int32_t reserved[4];
+} gik_template_info;
+int gik_template_get_info(const gik_template *t, gik_template_info *info);
 
 /* costgrd twins, batched over B problems.  d_Y, d_W, d_out: [B][N*k]; d_targets: [B][T]
  * (squared goal distance for EQ terms, psi_L / psi_U for hinge terms); d_f: [B].          */

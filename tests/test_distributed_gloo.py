@@ -83,9 +83,17 @@ def test_bench_self_launches_ranks_and_gathers():
     # weak-scaling default (BASELINE configs[1]): every rank brings its own 4096 goals
     w2 = _bench_line("--gpus", "2")
     assert w2["config"]["robot"] == "lwa4d" and w2["rows"] == 2 * 4096 and w2["scaling"] == "weak"
+    # ... and the default line (what the driver runs at every N) carries the other BASELINE workloads
+    # under "configs": the c4 / c5 tables gathered from two shards equal the one-rank tables
+    cf = w2["configs"]
+    assert set(cf) == {"c3", "c4", "c5"}             # (the 8192-goal share line is single-GPU only)
+    assert cf["c4"]["rows_sha"] == one["rows_sha"] and cf["c4"]["scaling"] == "strong"
+    assert cf["c3"]["rows"] == 2 * 4096 and cf["c3"]["scaling"] == "weak"
     # c5 shards the planar chain the same way (uneven world sizes included)
     p1, p3 = _bench_line("--gpus", "1", "--config", "c5"), _bench_line("--gpus", "3", "--config", "c5")
     assert p1["rows_sha"] == p3["rows_sha"] and p3["rows"] == 65536
+    assert cf["c5"]["rows_sha"] == p1["rows_sha"]
+    assert "configs" not in p1                       # explicit --config: that workload only
 
 
 def test_bench_refuses_a_wrong_world_size():
