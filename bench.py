@@ -281,7 +281,7 @@ class Bench:
         }
 
     def measure(self, cfg, robot_name, total, scaling, steps, warmup, serving_streams=0,
-                cpu=False, streams=1, intended=False):
+                cpu=False, n_streams=1, intended=False):
         if self.dry:
             return self.measure_dry(cfg, robot_name, total, scaling, steps, warmup)
         args, torch, gd, dev, rank, world = self.args, self.torch, self.gd, self.dev, self.rank, self.world
@@ -337,13 +337,13 @@ class Bench:
         torch.cuda.synchronize(dev)
         gd.barrier()
         torch.cuda.synchronize(dev)
-        streams = [torch.cuda.Stream(dev) for _ in range(streams)] if streams > 1 else None
+        streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else None
         t0 = time.perf_counter()
         for i in range(steps):
             if streams is None:
                 res = step(i)
             else:                      # every step is the same full batch; S of them are in flight
-                with torch.cuda.stream(streams[i % streams]):
+                with torch.cuda.stream(streams[i % n_streams]):
                     res = step(i)
         torch.cuda.synchronize(dev)
         gd.barrier()
@@ -359,13 +359,14 @@ class Bench:
                 ks.append(float(anch.template.lib.gik_anchored_last_solve_ms(anch.template._h)))
             kernel_ms = float(np.mean(ks))
         else:
-            kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+            ks = [float(a.elapsed_time(b)) for a, b in zip(ev0, ev1)]
+            kernel_ms = float(np.mean(ks))
 
         # Serving configuration, reported separately (NOT `value`): the same batches, S in flight on
         # separate HIP streams, so the straggler tail of one batch overlaps with the bulk of the next.
         serving = None
         S = serving_streams
-        if S > 1 and streams == 1 and dt / steps < 0.5:   # (skipped for multi-second batches)
+        if S > 1 and n_streams == 1 and dt / steps < 0.5:   # (skipped for multi-second batches)
             nb = 4 * S
             sv_streams = [torch.cuda.Stream(dev) for _ in range(S)]
             for s_ in sv_streams:                        # warm the per-stream allocations
@@ -440,7 +441,7 @@ class Bench:
                                ("RTR solve kernel (workgroup per problem) on targets / Y_init resident in "
                                 "HBM; goal assembly and joint recovery run on the host outside the "
                                 "timed region (graphs beyond the device pipeline, N > 128)"),
-                       "parallelism": f"shard{world}", "batches_in_flight": streams},
+                       "parallelism": f"shard{world}", "batches_in_flight": n_streams},
             "median_pos_err_m": float(np.median(pos)), "median_rot_err_rad": float(np.median(rot)),
             "p90_pos_err_m": float(np.percentile(pos, 90)),
             "success_rate": float(np.mean((pos < 0.01) & (rot < 0.01))),
@@ -456,7 +457,7 @@ class Bench:
                          "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
                          "frac_executed": executed_tf / FP64_PEAK_TFLOPS, "traffic": None,
                          "kernel": (f"rtr_wave_kernel<{k},{prob.template.maxdeg}>" if N * k <= 64
-                                    else f"rtr_block_kernel<{k}>"), "kernel_ms": kernel_ms,
+                                    else f"rtr_block_kernel<{k}>"), "kernel_ms": kernel_ms, "kernel_ms_per_step": ks,
                          "kernel_share_of_step": kernel_ms / (dt_local / steps * 1e3),
                          "flops_per_launch": flops, "flops_executed_per_launch": flops_exec,
                          "note": "fp64 vector ALU (the contract's \"mfma\" class: compute-bound, not HBM); "
@@ -540,7 +541,7 @@ def main():
     b = Bench(args)
     cfg, robot_name, total, scaling = workload(args, b.world)
     out = b.measure(cfg, robot_name, total, scaling, args.steps, args.warmup,
-                    serving_streams=args.serving_streams, cpu=True, streams=args.streams,
+                    serving_streams=args.serving_streams, cpu=True, n_streams=args.streams,
                     intended=args.intended)
     # The default invocation (`python bench.py [--gpus N]`, what the driver runs) also times the other
     # BASELINE workloads after the headline, a few steps each, and reports them under "configs" in

@@ -143,7 +143,10 @@ class BatchProblem:
     """Goal-independent data of solve_with_riemannian for one problem graph, prepared once:
     edge template, which squared distances depend on the goal, anchors, limits."""
 
-    def __init__(self, graph, use_limits=True, params=None, device=None, force_block_prepare=False):
+    def __init__(self, graph, use_limits=True, params=None, device=None, force_block_prepare=False,
+                 host_only=False):
+        """host_only: only the goal-independent host data (edge pattern, anchors, limits); no device
+        handle is created (term-set construction can then be inspected without a GPU)."""
         self.force_block_prepare = force_block_prepare
         self.graph = graph
         self.robot = graph.robot
@@ -176,9 +179,12 @@ class BatchProblem:
             self.psi_L, self.psi_U = graph.distance_bound_matrices()
         else:
             self.psi_L = self.psi_U = None
+        self.N = N
+        if host_only:
+            self.template, self.device_pipeline = None, False
+            return
         self.template = Template.from_matrices(self.omega, self.psi_L, self.psi_U, k=self.dim,
                                                use_limits=use_limits, device=device, params=params)
-        self.N = N
         self._attach_device_pipeline()
 
     def _attach_device_pipeline(self):
@@ -358,7 +364,9 @@ class AnchoredProblem:
     add_spherical_obstacle).  The initial point is the robot graph's own (bound smoothing + MDS
     without obstacles) fitted to the world frame by its anchors."""
 
-    def __init__(self, graph, params=None, device=None):
+    def __init__(self, graph, params=None, device=None, host_only=False):
+        """host_only: derive the term set only (no device handles) -- what tests/test_host_layer.py
+        compares with the reference's own edge construction (tests/golden/ur10_table_intended.npz)."""
         import copy
         from ..utils.constants import OBSTACLE, ROBOT, TYPE, MAIN_PREFIX
         from .. import _ffi
@@ -368,8 +376,8 @@ class AnchoredProblem:
         obstacles = [n for n in graph.node_ids if graph.nodes[n].get(TYPE) == OBSTACLE]
         bare = copy.deepcopy(graph)
         bare.clear_obstacles()
-        self.base = BatchProblem(bare, use_limits=True, params=params, device=device)
-        if not self.base.device_pipeline:
+        self.base = BatchProblem(bare, use_limits=True, params=params, device=device, host_only=host_only)
+        if not host_only and not self.base.device_pipeline:
             raise NotImplementedError("robot graph beyond the device pipeline")
         bp = self.base
         N = bp.N
@@ -393,15 +401,24 @@ class AnchoredProblem:
                     pin.append((fidx[i], r, _ffi.TERM_UPPER, pU[i, a]))
         self.obstacles = np.array([[*np.asarray(graph.nodes[o]["pos"], dtype=float), float(graph.nodes[o]["radius"])]
                                    for o in obstacles], dtype=float).reshape(-1, 4)
+        self.obstacle_names = obstacles
         obs = self.obstacles.copy()
         obs[:, 3] = obs[:, 3] ** 2                            # LOWER = radius  ->  psi_L = radius^2
         names = [bare.node_ids[i] for i in free]
+        # graph_base.py:205-211 as written: every node whose TYPE holds ROBOT and whose name starts
+        # with MAIN_PREFIX gets [BELOW], LOWER = radius towards the obstacle -- pinned to the
+        # reference's own lines by tools/capture_golden_intended.py (700 edges for UR10 + table: p0..p6
+        # x 100; p0 and p6 are constants here, so 5 x 100 hinges act on unknowns)
         mask = [int(n[0] == MAIN_PREFIX and ROBOT in bare.nodes[n].get(TYPE, [])) for n in names]
         pos = np.zeros((len(anchors), 3))
         pos[:len(bp.anchor_nodes)] = bp.anchor_pos
         self.free, self.anchors, self.pin = free, anchors, pin
+        self.free_names = names
         self.free_terms = (ti, tj, tk, target)
         self.obs_mask = np.array(mask, dtype=np.int32)
+        if host_only:
+            self.template = None
+            return
         self.template = Template(
             len(free), 3, ti, tj, tk, None, device=device, params=params,
             anchored=dict(anchor_pos=pos, n_goal_anchor=len(goal), term_target=target,

@@ -64,3 +64,46 @@ def report(section, payload):
     except Exception:
         pass
     print(section, json.dumps(payload))
+
+
+# ---- fixed-anchor formulation: explicit term lists and a plain numpy evaluation ----
+def anchored_terms(ap, goal_anchor):
+    """Explicit point-to-anchor term list (node, position, squared target, kind) of one problem:
+    pinned terms + one lower hinge per (p-node, obstacle)."""
+    pos_tab = np.zeros((len(ap.anchors), 3))
+    nb = len(ap.anchors) - 2
+    pos_tab[:nb] = ap.base.anchor_pos
+    pos_tab[nb:] = goal_anchor.reshape(2, 3)
+    node = [p[0] for p in ap.pin]
+    pos = [pos_tab[p[1]] for p in ap.pin]
+    tgt = [p[3] for p in ap.pin]
+    kind = [p[2] for p in ap.pin]
+    for i in np.nonzero(ap.obs_mask)[0]:
+        for o in ap.obstacles:
+            node.append(int(i)); pos.append(o[:3]); tgt.append(o[3] ** 2); kind.append(2)
+    return np.array(node, dtype=np.int32), np.array(pos), np.array(tgt), np.array(kind, dtype=np.int32)
+
+
+def anchored_numpy(ap, Nf, Y, W, goal_anchor):
+    """Plain fp64 reference of the anchored cost, egrad (= 1/2 grad f, costs.py convention) and
+    ehess: free-free terms + point-to-anchor terms."""
+    ti, tj, tk, target = ap.free_terms
+    f, G, H = 0.0, np.zeros_like(Y), np.zeros_like(Y)
+
+    def term(yi, wi, yj, wj, tgt, kind):
+        y, w = yi - yj, wi - wj
+        d = y @ y
+        u = tgt - d
+        act = kind == 1 or (kind == 2 and u > 0) or (kind == 3 and u < 0)
+        if not act:
+            return 0.0, 0 * y, 0 * y
+        c = d - tgt
+        return u * u, 2 * c * y, 2 * (2 * (y @ w) * y + c * w)
+    for i, j, k_, t in zip(ti, tj, tk, target):
+        df, dg, dh = term(Y[i], W[i], Y[j], W[j], t, k_)
+        f += df; G[i] += dg; G[j] -= dg; H[i] += dh; H[j] -= dh
+    node, pos, tgt, kind = anchored_terms(ap, goal_anchor)
+    for i, a, t, k_ in zip(node, pos, tgt, kind):
+        df, dg, dh = term(Y[i], W[i], a, 0 * a, t, k_)
+        f += df; G[i] += dg; H[i] += dh
+    return f, G, H

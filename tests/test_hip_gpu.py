@@ -1134,46 +1134,7 @@ def _anchored_setup():
     return robot, graph, ap, Nf
 
 
-def _anchored_terms(ap, goal_anchor):
-    """Explicit point-to-anchor term list (node, position, squared target, kind) of one problem:
-    pinned terms + one lower hinge per (p-node, obstacle)."""
-    pos_tab = np.zeros((len(ap.anchors), 3))
-    nb = len(ap.anchors) - 2
-    pos_tab[:nb] = ap.base.anchor_pos
-    pos_tab[nb:] = goal_anchor.reshape(2, 3)
-    node = [p[0] for p in ap.pin]
-    pos = [pos_tab[p[1]] for p in ap.pin]
-    tgt = [p[3] for p in ap.pin]
-    kind = [p[2] for p in ap.pin]
-    for i in np.nonzero(ap.obs_mask)[0]:
-        for o in ap.obstacles:
-            node.append(int(i)); pos.append(o[:3]); tgt.append(o[3] ** 2); kind.append(2)
-    return np.array(node, dtype=np.int32), np.array(pos), np.array(tgt), np.array(kind, dtype=np.int32)
-
-
-def _anchored_numpy(ap, Nf, Y, W, goal_anchor):
-    """Plain fp64 reference of the anchored cost, egrad (= 1/2 grad f, costs.py convention) and
-    ehess: free-free terms + point-to-anchor terms."""
-    ti, tj, tk, target = ap.free_terms
-    f, G, H = 0.0, np.zeros_like(Y), np.zeros_like(Y)
-
-    def term(yi, wi, yj, wj, tgt, kind):
-        y, w = yi - yj, wi - wj
-        d = y @ y
-        u = tgt - d
-        act = kind == 1 or (kind == 2 and u > 0) or (kind == 3 and u < 0)
-        if not act:
-            return 0.0, 0 * y, 0 * y
-        c = d - tgt
-        return u * u, 2 * c * y, 2 * (2 * (y @ w) * y + c * w)
-    for i, j, k_, t in zip(ti, tj, tk, target):
-        df, dg, dh = term(Y[i], W[i], Y[j], W[j], t, k_)
-        f += df; G[i] += dg; G[j] -= dg; H[i] += dh; H[j] -= dh
-    node, pos, tgt, kind = _anchored_terms(ap, goal_anchor)
-    for i, a, t, k_ in zip(node, pos, tgt, kind):
-        df, dg, dh = term(Y[i], W[i], a, 0 * a, t, k_)
-        f += df; G[i] += dg; H[i] += dh
-    return f, G, H
+from parity_util import anchored_numpy as _anchored_numpy, anchored_terms as _anchored_terms  # noqa: E402
 
 
 def test_anchored_kernel_known_answers(torch_cuda):
@@ -1209,6 +1170,29 @@ def test_anchored_kernel_known_answers(torch_cuda):
     assert np.array_equal(T.proj(Y, W).cpu().numpy(), W)                # Euclidean: proj is the identity
 
 
+def test_anchored_kernel_against_reference_fixture(torch_cuda):
+    """The anchored HIP kernels against REFERENCE code: tests/golden/ur10_table_intended.npz holds
+    lcost / lgrad / lhess of the reference's own loops on the N = 116 graph the reference builds when
+    the comparison of graph_base.py:207 is made to succeed (tools/capture_golden_intended.py), at
+    points whose anchor rows sit at their true positions.  Free rows: 1e-12."""
+    robot, graph, ap, Nf = _anchored_setup()
+    d = load_golden("ur10_table_intended")
+    assert list(d["node_ids"]) == list(graph.node_ids)
+    free = np.array(ap.free)
+    ga = ap.goal_anchors(d["T_goal"])[d["kat_goal"]]
+    Y, W = d["kat_Y"][:, free], d["kat_W"][:, free]
+    T = ap.template
+    f = T.cost(Y, ga).cpu().numpy()
+    G = T.grad(Y, ga).cpu().numpy()
+    H = T.hess(Y, W, ga).cpu().numpy()
+    assert d["kat_active_hinges"].min() >= 5
+    for t in range(len(f)):
+        Gr, Hr = d["kat_grad"][t][free], d["kat_hess"][t][free]
+        assert abs(f[t] - d["kat_cost"][t]) <= 1e-12 * d["kat_cost"][t]
+        assert np.abs(G[t] - Gr).max() <= 1e-12 * np.abs(Gr).max()
+        assert np.abs(H[t] - Hr).max() <= 1e-12 * np.abs(Hr).max()
+
+
 def test_anchored_trajectory_against_oracle(torch_cuda):
     """The anchored trust-region solve against its CPU twin (gik_o_rtr_solve_anchored) from the same
     start points: identical decisions and f, |grad| to 1e-8 for the first 5 outer iterations, same
@@ -1222,7 +1206,7 @@ def test_anchored_trajectory_against_oracle(torch_cuda):
     ga = ap.goal_anchors(Tg)
     Y0 = 0.5 * rng.randn(B, Nf, 3) + np.array([0.0, 0.0, 0.6])
     T = ap.template
-    r = T.solve(Y0, ga, trace_cap=16)
+    r = T.solve(Y0, ga, trace_cap=32)
     tr = {k: v.cpu().numpy() for k, v in r["trace"].items()}
     f, its = r["f"].cpu().numpy(), r["iterations"].cpu().numpy()
     ti, tj, tk, target = ap.free_terms
@@ -1234,17 +1218,23 @@ def test_anchored_trajectory_against_oracle(torch_cuda):
             pL[i, j] = pL[j, i] = t
         else:
             pU[i, j] = pU[j, i] = t
-    same_class = 0
+    from parity_util import assert_prefix_equal, first_divergence, report
+    same_class, k_hip = 0, []
     for b in range(B):
         node, pos, tgt, kind = _anchored_terms(ap, ga[b])
-        o = co.rtr_solve_anchored(Y0[b], D, om, pL, pU, node, pos, tgt, kind, traj_cap=16)
-        m = min(5, int(its[b]), o["iterations"])
-        for key in ("numit", "stop", "accept", "Delta"):
-            assert np.array_equal(tr[key][b][:m], o["traj"][key][:m]), (b, key)
-        assert np.allclose(tr["f_before"][b][:m], o["traj"]["f_before"][:m], rtol=1e-8, atol=0)
-        assert np.allclose(tr["gradnorm_after"][b][:m], o["traj"]["gradnorm_after"][:m], rtol=1e-8, atol=0)
+        o = co.rtr_solve_anchored(Y0[b], D, om, pL, pU, node, pos, tgt, kind, traj_cap=32)
+        n = min(32, int(its[b]), o["iterations"])
+        hip = {k: tr[k][b] for k in tr}
+        assert_prefix_equal(hip, o["traj"], min(5, n))                    # strict: every goal
+        k_hip.append(first_divergence(hip, o["traj"], n))                 # ... and how far it really goes
         same_class += int((f[b] < 1e-9) == (o["f(x)"] < 1e-9))
+    report("trajectory_prefix/ur10_table_intended/anchored", {"hip_leaves_oracle_at": k_hip,
+           "iterations_hip": its.tolist()})
     assert same_class >= B - 2
+    # the fixed-anchor problem is better conditioned than the quotient formulation (no gauge
+    # freedom): the two renderings stay the same computation (decisions identical, f and |grad| to
+    # 1e-8) well beyond the strict five iterations
+    assert np.median(k_hip) >= 8 and min(k_hip) >= 5, k_hip
 
 
 def test_anchored_pipeline(torch_cuda):
