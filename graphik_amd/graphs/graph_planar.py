@@ -1,11 +1,11 @@
-"""Distance-geometric problem graph of a planar revolute chain
-(graphik/graphs/graph_planar.py).  Node order p0, x, y, p1, ..., pn."""
+"""Distance-geometric problem graph of a planar revolute chain or tree
+(graphik/graphs/graph_planar.py).  Node order of a chain: p0, x, y, p1, ..., pn."""
 from math import sqrt
 
 import numpy as np
 
 from .graph_base import ProblemGraph, B_BELOW, B_EMPTY
-from ..utils.constants import BASE, END_EFFECTOR, POS, ROBOT, TYPE
+from ..utils.constants import BASE, END_EFFECTOR, POS, ROBOT, ROOT, TYPE
 from ..utils.lie import as_matrix
 from ..utils.utils import wraptopi
 
@@ -24,8 +24,14 @@ class ProblemGraphPlanar(ProblemGraph):
     planar_bounded = True
 
     def __init__(self, robot, params={}):
-        n = robot.n
-        super().__init__(robot, params, ["p0", "x", "y"] + [f"p{i}" for i in range(1, n + 1)])
+        # node order of nx.compose(base, structure) (graph_planar.py:17-23): p0, x, y, then the joints
+        # in the order the end effectors' paths visit them (a chain: p1, ..., pn)
+        ids = ["p0", "x", "y"]
+        for ee in robot.end_effectors:
+            for node in robot.kinematic_map[ROOT][ee]:
+                if node not in ids:
+                    ids.append(node)
+        super().__init__(robot, params, ids)
         # base (graph_planar.py:30-48); x axis mirrored as in the reference
         for name, pos, typ in (("p0", [0, 0], [BASE, ROBOT]), ("x", [-1, 0], [BASE]),
                                ("y", [0, 1], [BASE])):
@@ -34,13 +40,22 @@ class ProblemGraphPlanar(ProblemGraph):
         for u, v in (("p0", "x"), ("p0", "y"), ("x", "y")):
             d = np.linalg.norm(self.nodes[u][POS] - self.nodes[v][POS])
             self.set_edge(u, v, dist=d, lower=d, upper=d, bounded=B_EMPTY)
-        # structure (:50-88)
-        for i in range(1, n + 1):
-            d = np.linalg.norm(robot.nodes[f"p{i}"]["T0"].trans - robot.nodes[f"p{i - 1}"]["T0"].trans)
-            self.set_edge(f"p{i - 1}", f"p{i}", dist=d, lower=d, upper=d, bounded=B_EMPTY)
-            self.nodes[f"p{i}"][TYPE] = [ROBOT]
-        self.nodes[f"p{n}"][TYPE] += [END_EFFECTOR]
-        self.nodes[f"p{n - 1}"][TYPE] = self.nodes[f"p{n - 1}"].get(TYPE, []) + [END_EFFECTOR]
+        # structure (:50-88): one pass per end effector over its path from the root.  Re-adding a
+        # node resets its TYPE (networkx add_nodes_from updates the attribute dict), exactly as there.
+        self.structure_edges = []            # (pred, cur) in insertion order: parents before children
+        for ee in robot.end_effectors:
+            k_map = robot.kinematic_map[ROOT][ee]
+            for idx, cur in enumerate(k_map):
+                self.nodes[cur][TYPE] = [ROBOT] + ([BASE] if cur == ROOT else [])
+                if idx:
+                    pred = k_map[idx - 1]
+                    d = np.linalg.norm(robot.nodes[cur]["T0"].trans - robot.nodes[pred]["T0"].trans)
+                    self.set_edge(pred, cur, dist=d, lower=d, upper=d, bounded=B_EMPTY)
+                    if (pred, cur) not in self.structure_edges:
+                        self.structure_edges.append((pred, cur))
+                    if cur in robot.end_effectors:
+                        self.nodes[cur][TYPE] += [END_EFFECTOR]
+                        self.nodes[pred][TYPE] += [END_EFFECTOR]
         self.set_limits()
         self.root_angle_limits()
 
@@ -49,28 +64,31 @@ class ProblemGraphPlanar(ProblemGraph):
         return l1 + l2, sqrt(l1 ** 2 + l2 ** 2 - 2 * l1 * l2 * np.cos(np.pi - lim))
 
     def set_limits(self):
-        """two-apart pairs p_{i-2}, p_i (graph_planar.py:110-134)"""
-        for i in range(2, self.robot.n + 1):
-            l1, l2 = self.robot.l[f"p{i - 1}"], self.robot.l[f"p{i}"]
-            up, lo = self._limit(l1, l2, f"p{i}")
-            self.set_edge(f"p{i - 2}", f"p{i}", lower=lo, upper=up, bounded=B_BELOW)
+        """two-apart pairs u -> mid -> v along the tree (graph_planar.py:110-134): UPPER = l1 + l2,
+        LOWER from the (symmetric) limit of joint v, BOUNDED = "below"."""
+        robot = self.robot
+        for u in [n for n in self.node_ids if n in robot.children]:
+            for mid in robot.children[u]:
+                for v in robot.children[mid]:
+                    up, lo = self._limit(robot.l[mid], robot.l[v], v)
+                    self.set_edge(u, v, lower=lo, upper=up, bounded=B_BELOW)
 
     def root_angle_limits(self):
-        """x -- p1 (graph_planar.py:90-108)"""
+        """x -- every child of the root (graph_planar.py:90-108)"""
         l1 = np.linalg.norm(self.nodes["x"][POS])
-        l2 = self.dist[self.index("p0"), self.index("p1")]
-        up, lo = self._limit(l1, l2, "p1")
-        self.set_edge("x", "p1", lower=lo, upper=up, bounded=B_BELOW)
+        for node in self.robot.children[ROOT]:
+            l2 = self.dist[self.index(ROOT), self.index(node)]
+            up, lo = self._limit(l1, l2, node)
+            self.set_edge("x", node, lower=lo, upper=up, bounded=B_BELOW)
 
     def _pose_goal(self, T_goal):
-        """graph_planar.py:136-145: p_n and its predecessor are pinned by an SE(2) goal."""
+        """graph_planar.py:136-145: a goal pose pins its node and the node's parent."""
         pos = {}
         for u, T in T_goal.items():
-            i = int(u[1:])
-            if i == 0:
+            v = self.robot.parent.get(u)
+            if v is None:                     # the root has no predecessor: nothing is pinned
                 continue
             M = as_matrix(T)
-            v = f"p{i - 1}"
             d = self.dist[self.index(v), self.index(u)]
             pos[u] = M[:2, 2]
             pos[v] = M[:2, 2] - M[:2, 0] * d
@@ -78,14 +96,17 @@ class ProblemGraphPlanar(ProblemGraph):
 
     def joint_variables(self, G, T_final=None):
         P = G if isinstance(G, np.ndarray) else G.positions()
-        return self.robot.array_to_q(joint_variables_planar_batch(self, P[None])[0])
+        q = joint_variables_planar_batch(self, P[None])[0]
+        # keys in the order the reference's loop over the structure edges creates them
+        return {v: float(q[int(v[1:]) - 1]) for _, v in self.structure_edges}
 
     def get_pose(self, joint_angles, query_node):
         return self.robot.pose(joint_angles, query_node)
 
 
 def joint_variables_planar_batch(graph, P):
-    """graph_planar.py:147-176 over B realisations.  P [B,N,2] -> q [B,n]."""
+    """graph_planar.py:147-176 over B realisations (chains and trees).  P [B,N,2] -> q [B,n], column
+    i - 1 = joint p_i."""
     n = graph.robot.n
     ix = graph.index
     B = P.shape[0]
@@ -93,12 +114,12 @@ def joint_variables_planar_batch(graph, P):
     target = np.array([[0.0, 0.0], [-1.0, 0.0], [0.0, 1.0]])
     for b in range(B):
         R_, _ = best_fit_transform(np.vstack((P[b, ix("p0")], P[b, ix("x")], P[b, ix("y")])), target)
-        R = np.identity(2)
-        for i in range(1, n + 1):
-            diff = R_ @ (P[b, ix(f"p{i}")] - P[b, ix(f"p{i - 1}")])
-            sol = R.T @ (diff / np.linalg.norm(diff))
+        R = {ROOT: np.identity(2)}
+        for u, v in graph.structure_edges:
+            diff = R_ @ (P[b, ix(v)] - P[b, ix(u)])
+            sol = R[u].T @ (diff / np.linalg.norm(diff))
             th = np.arctan2(sol[1], sol[0])
-            q[b, i - 1] = wraptopi(th)
+            q[b, int(v[1:]) - 1] = wraptopi(th)
             c, s = np.cos(th), np.sin(th)
-            R = R @ np.array([[c, -s], [s, c]])
+            R[v] = R[u] @ np.array([[c, -s], [s, c]])
     return q

@@ -1,4 +1,4 @@
-"""Planar revolute chain (graphik/robots/robot_planar.py)."""
+"""Planar revolute chains and trees (graphik/robots/robot_planar.py)."""
 import numpy as np
 
 from .robot_base import Robot
@@ -26,16 +26,17 @@ class RobotPlanar(Robot):
             self.nodes[name]["S"] = np.hstack((np.cross(-w, q), w))[[0, 1, 5]]
 
     def _from_params(self):
-        """Zero-configuration frames from link lengths / offsets (robot_planar.py:51-60,
-        kinematics.py:22-36, geometry.py:8-17)."""
+        """Zero-configuration frames from the link lengths, accumulated along the path from the root
+        to every joint -- chains and trees (robot_planar.py:51-60, kinematics.py:21-35,
+        geometry.py:8-17).  As in the reference, the zero configuration stands in for the link
+        offsets: fk_tree_2d is called with theta = q = zero_configuration(), so params["theta"] is
+        not read."""
         self.l = self.params["link_lengths"]
-        th = self.params.get("theta", {k: 0.0 for k in self.l})
         T = {ROOT: SE2.identity()}
-        acc = SE2.identity()
-        for node in self.joint_ids[1:]:
-            R = SO2.from_angle(th[node])
-            acc = acc.dot(SE2(R, R.dot(np.array([self.l[node], 0.0]))))
-            T[node] = acc
+        for node in self.joint_ids:          # a parent precedes its children in joint_ids
+            if node == ROOT:
+                continue
+            T[node] = T[self.parent[node]].dot(SE2(SO2.identity(), np.array([self.l[node], 0.0])))
         return T
 
     def pose(self, joint_angles, query_node):

@@ -163,7 +163,15 @@ class BatchProblem:
         if self.dim == 3:
             self.goal_nodes = [graph.index(c + e[1:]) for e in self.end_effectors for c in "pq"]
         else:
-            self.goal_nodes = [graph.index(ee), graph.index(f"p{n - 1}")]
+            # planar (graph_planar.py:136-145): a goal pose pins its end effector and the end effector's
+            # parent; two end effectors of a tree may share that parent (one goal node then)
+            self.goal_nodes, self._goal_src = [], []
+            for e_i, e in enumerate(self.end_effectors):
+                for is_parent, name in ((0, e), (1, self.robot.parent[e])):
+                    if graph.index(name) not in self.goal_nodes:
+                        self.goal_nodes.append(graph.index(name))
+                        self._goal_src.append((e_i, is_parent, graph.dist[graph.index(self.robot.parent[e]),
+                                                                            graph.index(e)]))
         self.anchor_nodes = [i for i, name in enumerate(graph.node_ids)
                              if POS in graph.nodes[name] and i not in self.goal_nodes]
         self.anchor_pos = np.array([graph.nodes[graph.node_ids[i]][POS] for i in self.anchor_nodes],
@@ -191,9 +199,10 @@ class BatchProblem:
         """Hand the goal-independent pre/post-processing data to the device handle."""
         g, T = self.graph, self.template
         n = self.robot.n
-        if len(self.anchor_nodes) > 256 or self.N > 128 or len(self.end_effectors) > 4:
-            # beyond the device prepare / recover kernels (N <= 128, <= 4 end effectors): host
-            # pre/post-processing around the device solve
+        if len(self.anchor_nodes) > 256 or self.N > 128 or len(self.end_effectors) > 4 or \
+                (self.dim == 2 and self.multi_ee):
+            # beyond the device prepare / recover kernels (N <= 128, <= 4 end effectors, planar
+            # chains): host pre/post-processing around the device solve
             self.device_pipeline = False
             return
         goalset = set(self.goal_nodes)
@@ -266,10 +275,10 @@ class BatchProblem:
             p = T[:, :, :3, 3]
             q = p + T[:, :, :3, 2] * self.graph.axis_length
             return np.stack((p, q), axis=2).reshape(T.shape[0], -1, 3)   # p_e, q_e per end effector
-        ee, pred = self.goal_nodes
-        dist = self.graph.dist[pred, ee]
-        p = T[:, :2, 2]
-        return np.stack((p, p - T[:, :2, 0] * dist), axis=1)
+        if T.ndim == 3:
+            T = T[:, None]                               # one end effector
+        return np.stack([T[:, e_i, :2, 2] - (T[:, e_i, :2, 0] * dist if is_parent else 0.0)
+                         for e_i, is_parent, dist in self._goal_src], axis=1)
 
     def assemble(self, T_goals):
         """D_goal, LOWER, UPPER [B,N,N] for a batch of goals (from_pose + graph_complete_edges)."""

@@ -65,3 +65,22 @@ def make_graph(name):
                              "joint_limits_lower": list_to_variable_dict(-lim), "num_joints": n})
         return robot, ProblemGraphPlanar(robot)
     raise KeyError(name)
+
+
+def planar_tree(which):
+    """(robot, graph) of a planar TREE of tests/golden/planar_tree.npz (tools/capture_golden_planar_tree.py):
+    "y5" = p0 - p1 - {p2 - p3, p4 - p5}, "bin2" = balanced binary tree of height 2."""
+    from graphik_amd.robots import RobotPlanar
+    from graphik_amd.graphs import ProblemGraphPlanar
+    from graphik_amd.utils import list_to_variable_dict
+    d = load_golden("planar_tree")
+    parents = {}
+    for e in d[f"{which}_parents_flat"]:
+        u, v = str(e).split(">")
+        parents.setdefault(u, []).append(v)
+    lim = d[f"{which}_limits"]
+    robot = RobotPlanar({"link_lengths": list_to_variable_dict(d[f"{which}_link_lengths"]),
+                         "num_joints": len(lim), "parents": parents,
+                         "joint_limits_upper": list_to_variable_dict(lim),
+                         "joint_limits_lower": list_to_variable_dict(-lim)})
+    return robot, ProblemGraphPlanar(robot)

@@ -1363,3 +1363,29 @@ def test_anchored_near_lists_are_bit_identical(torch_cuda):
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
     assert (outs[0]["f"] < 1e-9).mean() > 0.7
+
+
+@pytest.mark.parametrize("which", ["y5", "bin2"])
+def test_planar_tree_solve_batch(torch_cuda, which):
+    """Planar TREES (graph_planar.py:50-88; several end effectors, possibly sharing their parent):
+    host goal assembly + bound smoothing + initial point, device trust-region solve, host
+    joint_variables -- every end effector of the recovered configuration reaches its goal pose; and
+    the drop-in call with a {end effector: pose} dict."""
+    from conftest import planar_tree
+    from graphik_amd.solvers.riemannian_solver import solve_batch, solve_with_riemannian
+    robot, graph = planar_tree(which)
+    rng = np.random.RandomState(6)
+    lb, ub = robot.limits_arrays()
+    B = 64
+    Q = lb + (ub - lb) * rng.rand(B, robot.n)
+    Tg = np.stack([[robot.pose(robot.array_to_q(q), ee).as_matrix() for ee in robot.end_effectors] for q in Q])
+    q, Y, info = solve_batch(graph, Tg, use_limits=True)
+    assert Y.shape == (B, graph.number_of_nodes(), 2) and q.shape == (B, robot.n)
+    assert np.all(np.isfinite(Y)) and np.all(info["stop"] != 2)
+    ok = (info["pos_err"] < 0.01) & (info["rot_err"] < 0.01)     # worst end effector per goal
+    assert ok.mean() > 0.9, ok.mean()
+    assert np.median(info["pos_err"]) < 1e-4
+    T_goal = {ee: robot.pose(robot.array_to_q(Q[0]), ee) for ee in robot.end_effectors}
+    q_sol, Y1 = solve_with_riemannian(graph, T_goal)
+    for ee in robot.end_effectors:
+        assert np.linalg.norm(robot.pose(q_sol, ee).trans - T_goal[ee].trans) < 1e-3

@@ -54,20 +54,7 @@ def test_batched_preprocessing_equals_single(name):
     d = load_golden(name)
     robot, graph = make_graph(name)
     use_lim = bool(int(d["use_limits"]))
-    prob = BatchProblem.__new__(BatchProblem)  # host part only: skip the device template
-    prob.graph, prob.robot, prob.dim, prob.use_limits = graph, robot, graph.dim, use_lim
-    n = robot.n
-    prob.goal_nodes = [graph.index(f"p{n}"), graph.index(f"q{n}" if graph.dim == 3 else f"p{n-1}")]
-    from graphik_amd.utils.constants import POS
-    prob.anchor_nodes = [i for i, nm in enumerate(graph.node_ids)
-                         if POS in graph.nodes[nm] and i not in prob.goal_nodes]
-    prob.anchor_pos = np.array([graph.nodes[graph.node_ids[i]][POS] for i in prob.anchor_nodes])
-    G0 = graph.from_pose(robot.pose(robot.zero_configuration(), f"p{n}"))
-    prob.omega = dgp.adjacency_matrix_from_graph(G0)
-    prob.base_D = dgp.distance_matrix_from_graph(G0)
-    prob.base_lower = np.where(G0.edge, G0.lower, np.nan)
-    prob.base_upper = np.where(G0.edge, G0.upper, np.nan)
-    prob.N = graph.number_of_nodes()
+    prob = BatchProblem(graph, use_limits=use_lim, host_only=True)   # host part only: no device template
     D, lo, up = prob.assemble(d["T_goal"])
     assert np.array_equal(prob.omega, d["omega"])
     assert np.abs(D - d["D_goal"]).max() < 1e-14 * max(1.0, np.abs(d["D_goal"]).max())
@@ -294,3 +281,89 @@ def test_randomized_links_match_reference():
         plain, _ = ld()
         assert np.abs(T - plain.T0_array()).max() > 1e-3                 # it does change the arm
         assert graph.number_of_nodes() == 2 * robot.n + 4
+
+
+# ---- planar trees (graph_planar.py:50-88; ADVICE r2: they used to build a silently wrong model) -----
+@pytest.mark.parametrize("which", ["y5", "bin2"])
+def test_planar_tree_graph_matches_reference(which):
+    """Topology, node order, zero-configuration frames, every edge attribute, psi_L / psi_U, and per
+    seed the random configuration, poses, realization, joint_variables, the goal graph's D_goal /
+    omega and bound_smoothing of two planar trees against the reference's RobotPlanar /
+    ProblemGraphPlanar (tests/golden/planar_tree.npz, tools/capture_golden_planar_tree.py)."""
+    from conftest import planar_tree
+    from graphik_amd.graphs.graph_base import B_ABSENT, B_EMPTY, B_NOEDGE
+    d = load_golden("planar_tree")
+    g = lambda k: d[f"{which}_{k}"]   # noqa: E731
+    robot, graph = planar_tree(which)
+    assert robot.joint_ids == list(g("joint_ids")) and robot.end_effectors == list(g("end_effectors"))
+    assert graph.node_ids == list(g("node_ids")) and not robot.is_chain
+    T0 = np.stack([robot.nodes[j]["T0"].as_matrix() for j in robot.joint_ids])
+    assert np.abs(T0 - g("T0")).max() < 1e-14
+    for key, M in (("G_dist", graph.dist), ("G_lower", graph.lower), ("G_upper", graph.upper)):
+        assert np.array_equal(np.isnan(M), np.isnan(g(key))), key
+        assert np.nanmax(np.abs(M - g(key))) < 1e-14, key
+    code = np.where((graph.bounded == B_ABSENT) | (graph.bounded == B_EMPTY), 0, graph.bounded)
+    assert np.array_equal(np.where(graph.bounded == B_NOEDGE, -1, code), g("G_bounded"))
+    pL, pU = graph.distance_bound_matrices()
+    assert np.abs(pL - g("psi_L")).max() < 1e-14 and np.abs(pU - g("psi_U")).max() < 1e-14
+    for s in range(len(g("q_goal"))):
+        np.random.seed(s)
+        q = robot.random_configuration()
+        assert np.array_equal([q[j] for j in robot.joint_ids[1:]], g("q_goal")[s])
+        T_goal = {ee: robot.pose(q, ee) for ee in robot.end_effectors}
+        for i, ee in enumerate(robot.end_effectors):
+            assert np.abs(T_goal[ee].as_matrix() - g("T_goal")[s][i]).max() < 1e-13
+        G = graph.realization(q)
+        assert np.abs(G.positions() - g("X")[s]).max() < 1e-13
+        q_rec = graph.joint_variables(G)
+        assert list(q_rec) == [v for _, v in graph.structure_edges]
+        assert np.abs(np.array([q_rec[j] for j in robot.joint_ids[1:]]) - g("q_rec")[s]).max() < 1e-12
+        Gd = graph.from_pose(T_goal)
+        assert np.abs(dgp.distance_matrix_from_graph(Gd) - g("D_goal")[s]).max() < 1e-13
+        assert np.array_equal(dgp.adjacency_matrix_from_graph(Gd), g("omega"))
+        lb, ub = dgp.bound_smoothing(Gd)
+        assert np.abs(lb - g("lb")[s]).max() < 1e-12 and np.abs(ub - g("ub")[s]).max() < 1e-12
+
+
+def test_planar_tree_round_trip_and_batch_assembly():
+    """The reference's round-trip property (tests/test_joint_variables.py:139-156, this time on real
+    trees: balanced binary trees of height 2..4 built as there, WITH their parents) and the batched
+    goal assembly of BatchProblem against the per-goal graph path."""
+    import networkx as nx
+    from conftest import planar_tree
+    from graphik_amd.robots import RobotPlanar
+    from graphik_amd.graphs import ProblemGraphPlanar
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    from graphik_amd.utils import list_to_variable_dict
+    np.random.seed(3)
+    for height in (2, 3, 4):
+        gen = nx.balanced_tree(2, height, create_using=nx.DiGraph)
+        gen = nx.relabel_nodes(gen, {node: f"p{node}" for node in gen})
+        n = gen.number_of_edges()
+        params = {"link_lengths": list_to_variable_dict(np.ones(n)), "num_joints": n,
+                  "parents": {k: v for k, v in nx.to_dict_of_lists(gen).items() if v}}
+        robot = RobotPlanar(params)
+        graph = ProblemGraphPlanar(robot)
+        assert len(robot.end_effectors) == 2 ** height
+        for _ in range(10):
+            q_goal = robot.random_configuration()
+            q_rec = graph.joint_variables(graph.realization(q_goal))
+            np.testing.assert_allclose([q_goal[k] for k in sorted(q_goal)], [q_rec[k] for k in sorted(q_goal)],
+                                       rtol=1e-5)
+    for which in ("y5", "bin2"):
+        robot, graph = planar_tree(which)
+        prob = BatchProblem(graph, use_limits=True, host_only=True)
+        rng = np.random.RandomState(1)
+        lb, ub = robot.limits_arrays()
+        Q = lb + (ub - lb) * rng.rand(6, robot.n)
+        Tg = np.stack([[robot.pose(robot.array_to_q(q), ee).as_matrix() for ee in robot.end_effectors] for q in Q])
+        D, lo, up = prob.assemble(Tg)
+        for b in range(len(Q)):
+            Gd = graph.from_pose({ee: Tg[b, i] for i, ee in enumerate(robot.end_effectors)})
+            assert np.abs(dgp.distance_matrix_from_graph(Gd) - D[b])[prob.omega != 0].max() < 1e-13
+            assert np.array_equal(dgp.adjacency_matrix_from_graph(Gd), prob.omega)
+            l1, u1 = dgp.bound_smoothing(Gd)
+            l2, u2 = dgp.floyd_warshall_bounds(lo[b:b + 1], up[b:b + 1])
+            assert np.abs(l1 - l2[0]).max() < 1e-12 and np.abs(u1 - u2[0]).max() < 1e-12
+        qr = prob.joint_variables(np.stack([graph.realization(robot.array_to_q(q)).positions() for q in Q]), Tg)
+        assert np.abs(np.mod(qr - Q + np.pi, 2 * np.pi) - np.pi).max() < 1e-9

@@ -371,19 +371,19 @@ def host():
 @scenario
 def lwa4d():
     robot, graph = load_schunk_lwa4d()
-    run_scenario("lwa4d", robot, graph, seeds=list(range(16)), traj_goals=16, loop_goals=3)
+    run_scenario("lwa4d", robot, graph, seeds=list(range(16)), traj_goals=16, loop_goals=16)
 
 
 @scenario
 def ur10():
     robot, graph = load_ur10()
-    run_scenario("ur10", robot, graph, seeds=list(range(12)), traj_goals=12, loop_goals=2)
+    run_scenario("ur10", robot, graph, seeds=list(range(12)), traj_goals=12, loop_goals=12)
 
 
 @scenario
 def kuka():
     robot, graph = load_kuka()
-    run_scenario("kuka", robot, graph, seeds=list(range(12)), traj_goals=12, loop_goals=2)
+    run_scenario("kuka", robot, graph, seeds=list(range(12)), traj_goals=12, loop_goals=12)
 
 
 @scenario
