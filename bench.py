@@ -62,7 +62,7 @@ def algorithmic_flops(N, k, T, n_inner, n_outer, n_accept):
 def algorithmic_bytes(N, k, T):
     """HBM bytes the solve kernel must move per IK problem: T targets + Y_init in, Y_sol + stats
     out (SURVEY 8(d) counts the pipeline-level 616 B/solve; the dominant kernel alone sees this)."""
-    return 8 * (T + 2 * N * k) + 32
+    return 8 * (T + 2 * N * k) + 48          # (+ the 48-byte gik_stats record)
 
 
 def parse_args(argv=None):

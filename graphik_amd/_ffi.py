@@ -48,10 +48,10 @@ SOLVER_TRUST_REGIONS, SOLVER_CONJUGATE_GRADIENT = 0, 1
 
 
 class Stats(C.Structure):
-    """gik_stats (40 bytes per problem); engine.py sizes and decodes the stats buffer from this."""
+    """gik_stats (48 bytes per problem); engine.py sizes and decodes the stats buffer from this."""
     _fields_ = [("f", C.c_double), ("gradnorm", C.c_double), ("iterations", C.c_int32),
                 ("inner_total", C.c_int32), ("stop", C.c_int32), ("n_accept", C.c_int32),
-                ("inner_executed", C.c_int32), ("flags", C.c_int32)]
+                ("inner_executed", C.c_int32), ("flags", C.c_int32), ("stepsize", C.c_double)]
 
 
 STATS_BYTES = C.sizeof(Stats)

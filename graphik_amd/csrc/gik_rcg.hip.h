@@ -111,14 +111,17 @@ __device__ inline void rcg_solve_one(Ctx &cx, const CgParams &p, const gik_trace
       } else if (p.beta_type == CG_POLAK_RIBIERE) {
         beta = fmax(0.0, v[3] / gradPgrad);
       } else if (p.beta_type == CG_HESTENES_STIEFEL) {
-        beta = (v[2] == 0.0) ? 1.0 : fmax(0.0, v[3] / v[2]);
+        // numpy scalars never raise ZeroDivisionError, so pymanopt's `except: beta = 1` arm is dead
+        // code on this path: a zero denominator gives inf / nan and Python's max(0, .) keeps inf,
+        // maps -inf and nan to 0 -- which is what fmax does
+        beta = fmax(0.0, v[3] / v[2]);
       } else {                                        // Hager-Zhang
         const double deno = v[2];
         double numo = v[3];
         numo -= 2.0 * v[4] * v[5] / deno;
         beta = numo / deno;
         const double eta_HZ = -1.0 / (sqrt(v[6]) * fmin(0.01, gradnorm));
-        beta = fmax(beta, eta_HZ);
+        beta = (eta_HZ > beta) ? eta_HZ : beta;       // Python's max(beta, eta_HZ): a NaN beta stays NaN
       }
       desc = fma(beta, tdesc, -ng);
     }

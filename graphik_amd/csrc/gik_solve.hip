@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
       s.n_accept = n_accept;
       s.inner_executed = ro.inner_executed;
       s.flags = 0;
+      s.stepsize = ro.Delta;
       a.stats[b] = s;
     }
   }
@@ -258,6 +259,7 @@ __global__ void __launch_bounds__(WAVE, 2) rcg_wave_kernel(SolveArgs a) {
       s.n_accept = ro.n_accept;
       s.inner_executed = ro.inner_executed;
       s.flags = 0;
+      s.stepsize = ro.Delta;
       a.stats[b] = s;
     }
   }
@@ -410,6 +412,7 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
       s.n_accept = ro.n_accept;
       s.inner_executed = ro.inner_executed;
       s.flags = cx.lowrank ? 1 : 0;
+      s.stepsize = ro.Delta;
       a.stats[b] = s;
       if (a.slice_its > 0) __hip_atomic_fetch_add(a.q_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -446,6 +449,7 @@ __global__ void __launch_bounds__(BLOCK_NT) rcg_block_kernel(SolveArgs a, int SL
       s.n_accept = ro.n_accept;
       s.inner_executed = ro.inner_executed;
       s.flags = cx.lowrank ? 1 : 0;
+      s.stepsize = ro.Delta;
       a.stats[b] = s;
     }
   }

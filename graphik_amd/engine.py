@@ -64,7 +64,7 @@ def _alloc_stats(B, device):
 def _decode_stats(stats):
     """Views of the gik_stats fields (layout taken from _ffi.Stats, i.e. from the header)."""
     ints = stats.view(torch.int32)
-    out = {"f": stats[:, _ffi.STATS_F64["f"]], "gradnorm": stats[:, _ffi.STATS_F64["gradnorm"]]}
+    out = {name: stats[:, col] for name, col in _ffi.STATS_F64.items()}      # f, gradnorm, stepsize
     for name in ("iterations", "inner_total", "stop", "n_accept", "inner_executed", "flags"):
         out[name] = ints[:, _ffi.STATS_I32[name]]
     return out

@@ -132,6 +132,7 @@ class RiemannianSolver:
                 "stop": res["stop"].cpu().numpy()}
         if T.solver == "ConjugateGradient":      # pymanopt's final_values carry the last step size
             info["costevals"] = info.pop("inner_iterations")
+            info["stepsize"] = res["stepsize"].cpu().numpy()
         if not batched:
             info = {k: (v[0] if k == "x" else v[0].item()) for k, v in info.items()}
             info["stop_reason"] = _STOP_REASONS[int(info["stop"])]

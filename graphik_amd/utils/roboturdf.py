@@ -1,8 +1,9 @@
 """Robot loaders (graphik/utils/roboturdf.py).
 
-`load_schunk_lwa4d / load_ur10 / load_kuka` return (robot, graph) like the reference's loaders
-(roboturdf.py:314-371) from kinematic constants packaged under graphik_amd/data/robots (frames
-at zero configuration extracted from the reference's URDF data; see tools/export_robot_data.py).
+`load_schunk_lwa4d / load_ur10 / load_kuka / load_schunk_lwa4p / load_panda` return (robot, graph)
+like the reference's loaders (roboturdf.py:299-371) from kinematic constants packaged under
+graphik_amd/data/robots (frames at zero configuration extracted from the reference's URDF data; see
+tools/export_robot_data.py, tools/capture_golden_loaders.py).
 `RobotURDF` is an own kinematics-only URDF reader for user-supplied files.
 """
 import json
@@ -66,6 +67,16 @@ def load_ur10(limits=None, randomized_links=False, randomize_percentage=0.4):
 
 def load_kuka(limits=None, randomized_links=False, randomize_percentage=0.4):
     return _make(*_packaged("kuka"), limits, randomized_links, randomize_percentage)
+
+
+def load_schunk_lwa4p(limits=None, randomized_links=False, randomize_percentage=0.4):
+    """Schunk LWA4P, 6 joints (roboturdf.py:299-312)."""
+    return _make(*_packaged("lwa4p"), limits, randomized_links, randomize_percentage)
+
+
+def load_panda(limits=None, randomized_links=False, randomize_percentage=0.4):
+    """Franka Panda arm, 7 joints (roboturdf.py:343-356)."""
+    return _make(*_packaged("panda"), limits, randomized_links, randomize_percentage)
 
 
 def load_truncated_ur10(n):

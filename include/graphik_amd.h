@@ -135,7 +135,9 @@ typedef struct {
   int32_t flags;       /* bit 0: workgroup kernels, rigid clique: the clique's target distances were
                           those of a point set in R^3 and its dense D w product was replaced by
                           moments (informational; results agree to round-off either way)   */
-} gik_stats;            /* 40 bytes                                                         */
+  double stepsize;     /* ConjugateGradient: step of the last line search (the `stepsize` entry of
+                          pymanopt's final_values); TrustRegions: trust-region radius at return  */
+} gik_stats;            /* 48 bytes                                                         */
 
 /* Optional per-outer-iteration trace (device arrays of B x cap; pass NULL to disable). */
 typedef struct {

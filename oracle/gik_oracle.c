@@ -784,7 +784,10 @@ int gik_o_cg_solve(double *Y, const double *D_goal, const double *omega, const d
       } else if (p->beta_type == 2) {                /* HestenesStiefel */
         for (int t = 0; t < n; ++t) diff[t] = newgrad[t] - oldgrad[t];
         const double den = dot(diff, tdesc, n);
-        beta = (den == 0.0) ? 1.0 : fmax(0.0, dot(newgrad, diff, n) / den);
+        /* pymanopt: `try: beta = max(0, ip_diff / inner(diff, desc_dir)) except ZeroDivisionError:
+         * beta = 1` -- numpy scalars never raise, so den == 0 gives inf / nan and Python's
+         * max(0, .) keeps inf and maps -inf and nan to 0: exactly fmax */
+        beta = fmax(0.0, dot(newgrad, diff, n) / den);
       } else {                                       /* HagerZhang */
         for (int t = 0; t < n; ++t) diff[t] = newgrad[t] - oldgrad[t];
         /* Poldgrad = man.transp(x, newx, Pgrad) = oldgrad; Pdiff = Pnewgrad - Poldgrad = diff */
@@ -794,7 +797,7 @@ int gik_o_cg_solve(double *Y, const double *D_goal, const double *omega, const d
         beta = numo / deno;
         const double desc_dir_norm = sqrt(dot(tdesc, tdesc, n));
         const double eta_HZ = -1 / (desc_dir_norm * fmin(0.01, gradnorm));
-        beta = fmax(beta, eta_HZ);
+        beta = (eta_HZ > beta) ? eta_HZ : beta; /* Python max(beta, eta_HZ): a NaN beta stays NaN */
       }
       for (int t = 0; t < n; ++t) desc[t] = -newgrad[t] + beta * tdesc[t];
     }

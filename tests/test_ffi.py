@@ -24,14 +24,14 @@ def test_header_symbols_are_bound_and_exported():
 def test_struct_layouts_match_header():
     import ctypes as C
     from graphik_amd import _ffi
-    # gik_stats: the header says 40 bytes; parse its field list and compare with the ctypes mirror
+    # gik_stats: the header says 48 bytes; parse its field list and compare with the ctypes mirror
     hdr = open(os.path.join(REPO, "include", "graphik_amd.h")).read()
     body = re.search(r"typedef struct \{([^}]*)\} gik_stats;", hdr).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = re.findall(r"\b(double|int32_t)\s+(\w+)\s*;", body)
     assert [n for _, n in fields] == [n for n, _ in _ffi.Stats._fields_]
-    assert sum(8 if t == "double" else 4 for t, _ in fields) == 40 == C.sizeof(_ffi.Stats)
-    assert _ffi.STATS_I32["inner_executed"] == 8 and _ffi.STATS_F64["gradnorm"] == 1
+    assert sum(8 if t == "double" else 4 for t, _ in fields) == 48 == C.sizeof(_ffi.Stats)
+    assert _ffi.STATS_I32["inner_executed"] == 8 and _ffi.STATS_F64["gradnorm"] == 1 and _ffi.STATS_F64["stepsize"] == 5
     # descriptor structs: same fields in the same order with the same scalar types as the header
     ctype_of = {"double": C.c_double, "int32_t": C.c_int32}
     for cname, mirror in (("gik_template_desc", _ffi.TemplateDesc), ("gik_pipeline_desc", _ffi.PipelineDesc),

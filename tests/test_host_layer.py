@@ -367,3 +367,31 @@ def test_planar_tree_round_trip_and_batch_assembly():
             assert np.abs(l1 - l2[0]).max() < 1e-12 and np.abs(u1 - u2[0]).max() < 1e-12
         qr = prob.joint_variables(np.stack([graph.realization(robot.array_to_q(q)).positions() for q in Q]), Tg)
         assert np.abs(np.mod(qr - Q + np.pi, 2 * np.pi) - np.pi).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", ["lwa4p", "panda"])
+def test_remaining_loaders_match_reference(name):
+    """load_schunk_lwa4p / load_panda (roboturdf.py:299-312, 343-356): template, frames, and
+    configuration -> pose -> realization -> joint_variables tuples against the reference's loaders
+    (tests/golden/loaders_extra.npz, tools/capture_golden_loaders.py)."""
+    from graphik_amd.utils.roboturdf import load_panda, load_schunk_lwa4p
+    d = load_golden("loaders_extra")
+    g = lambda k: d[f"{name}_{k}"]   # noqa: E731
+    robot, graph = {"lwa4p": load_schunk_lwa4p, "panda": load_panda}[name]()
+    assert robot.n == int(g("n_joints")) and graph.node_ids == list(g("node_ids"))
+    assert np.abs(robot.T0_array() - g("T0")).max() == 0.0
+    assert _same(graph.dist, g("G_dist")) and _same(graph.lower, g("G_lower")) and _same(graph.upper, g("G_upper"))
+    assert np.array_equal(np.where(graph.bounded == 5, 0, graph.bounded), g("G_bounded"))
+    L, U = graph.distance_bound_matrices()
+    assert np.array_equal(L, g("psi_L")) and np.array_equal(U, g("psi_U"))
+    n = robot.n
+    for s_ in range(len(g("q_goal"))):
+        np.random.seed(s_)
+        q = robot.random_configuration()
+        assert np.array_equal(robot.q_to_array(q), g("q_goal")[s_])
+        T = robot.pose(q, f"p{n}")
+        assert np.abs(T.as_matrix() - g("T_goal")[s_]).max() < 1e-13
+        G = graph.realization(q)
+        assert np.abs(G.positions() - g("X")[s_]).max() < 1e-13
+        qr = graph.joint_variables(G, {f"p{n}": T})
+        assert np.abs(robot.q_to_array(qr) - g("q_rec")[s_]).max() < 1e-9
