@@ -211,8 +211,11 @@ def test_finals_statistical_3d(torch_cuda, name, path):
       * on every goal where the reference's two paths agree to 1e-3, HIP agrees with it to 1e-3;
       * UR10 (6 DOF, isolated solutions): every converged goal to 1e-3 (block path: 90 % to 1e-3,
         all to 5e-3 -- one slowly converging goal, f = 1e-13, sits at 1.3e-3);
-      * the 7-DOF arms in distribution: median |dq| against the reference no larger than 3x the
-        oracle's own median |dq| against it (or than the reference's two paths are apart), and
+      * the 7-DOF arms in distribution, MEDIAN against MEDIAN over all captured goals (the loop path
+        is captured for every goal since round 3): median |dq| of HIP against the reference's numpy
+        path no larger than 3x the larger of (the oracle's median |dq| against it, the median |dq|
+        between the reference's own two paths) -- KUKA: reference pair 3.0e-3, oracle 2.0e-3,
+        wavefront kernel 8.4e-3, workgroup kernel 2.6e-3; LWA4D: 5.7e-4 / 6.6e-4 / 5.0e-4 -- and
         nothing beyond the self-motion scale (0.2 rad) except where the oracle leaves the
         reference's branch as well;
       * convergence class per goal, iteration counts and EE errors as before.
@@ -237,7 +240,8 @@ def test_finals_statistical_3d(torch_cuda, name, path):
     o = co.rtr_solve_batch(d["Y_init"], d["D_goal"], d["omega"], d["psi_L"], d["psi_U"], True, fast=False)
     dq_orc = wrap_abs(joint_variables_revolute_batch(graph, o["x"], d["T_goal"]) - d["q_sol"]).max(axis=1)
     nl = d["loop_q_sol"].shape[0]
-    dq_ref = wrap_abs(d["q_sol"][:nl] - d["loop_q_sol"]).max(axis=1)
+    assert nl == len(d["q_sol"])                     # loop path captured for every goal
+    dq_ref = wrap_abs(d["q_sol"] - d["loop_q_sol"]).max(axis=1)
     report(f"finals_dq/{name}/{path}", {
         "reference_np_vs_loops": dq_ref.tolist(), "hip_vs_reference_np": dq.tolist(),
         "oracle_vs_reference_np": dq_orc.tolist(), "converged": conv.astype(int).tolist(),
@@ -251,7 +255,9 @@ def test_finals_statistical_3d(torch_cuda, name, path):
         else:
             assert np.mean(dq[conv] < 1e-3) >= 0.9 and np.all(dq[conv] < 5e-3), dq
     else:
-        assert np.median(dq[conv]) <= max(3 * np.median(dq_orc[conv]), dq_ref.max()) + 1e-4, (dq, dq_orc)
+        both = conv & (d["loop_f_sol"] < 1e-9)
+        bar = 3 * max(np.median(dq_orc[conv]), np.median(dq_ref[both]))
+        assert np.median(dq[conv]) <= bar, (np.median(dq[conv]), np.median(dq_orc[conv]), np.median(dq_ref[both]))
         assert np.all((dq[conv] < 0.2) | (dq_orc[conv] > 0.05)), (dq, dq_orc)
 
 
@@ -288,8 +294,9 @@ def test_effort_parity_ur10(torch_cuda):
     """Same work as the reference's algorithm, not only the same answers: on random UR10 goals no
     tCG solve runs into maxinner (the reference's never do; a search direction that keeps the
     vertical round-off of the gradient does, late in a solve, in one solve out of five), outer
-    iterations agree in distribution and the Hessian products stay within 15 % of the oracle's
-    (measured +8 %: the column-form product puts its round-off outside range(J^T))."""
+    iterations agree in distribution and the Hessian products stay within 12 % of the oracle's
+    (measured +8 %: the column-form product puts its round-off outside range(J^T); the
+    bound was 15 % in round 2)."""
     from oracle import c_oracle as co
     from graphik_amd.solvers.riemannian_solver import BatchProblem
     robot, graph = make_graph("ur10")
@@ -309,7 +316,7 @@ def test_effort_parity_ur10(torch_cuda):
     hv_o = np.array([x["inner_total"] for x in o])
     assert np.array_equal(its < 3000, its_o < 3000)
     assert 0.9 < np.median(its) / np.median(its_o) < 1.1
-    assert 0.9 < hv.sum() / hv_o.sum() < 1.15, (hv.sum(), hv_o.sum())
+    assert 0.95 < hv.sum() / hv_o.sum() < 1.12, (hv.sum(), hv_o.sum())
 
 
 # ---- batched pipeline -------------------------------------------------------------------------
@@ -654,9 +661,9 @@ def test_end_to_end_statistics_from_device_init(torch_cuda, name):
     report(f"end_to_end_statistics/{name}", stats)
     assert abs(conv.mean() - conv_o.mean()) < 0.03
     assert abs(succ.mean() - succ_o.mean()) < 0.03
-    assert 0.85 < np.median(its) / np.median(its_o) < 1.15
+    assert 0.93 < np.median(its) / np.median(its_o) < 1.07      # measured 0.997 .. 1.000
     assert 0.75 < np.percentile(its, 90) / np.percentile(its_o, 90) < 1.33
-    assert 0.8 < hv.sum() / hv_o.sum() < 1.25
+    assert 0.92 < hv.sum() / hv_o.sum() < 1.12      # measured 1.055 (KUKA), 1.069 (LWA4D), 1.079 (UR10)
     assert 0.7 < np.median(pos) / np.median(pos_o) < 1.4
 
 

@@ -162,7 +162,8 @@ def test_urdf_reader_reproduces_packaged_constants(name, urdf):
 
 def test_bench_algorithmic_work_matches_survey():
     """bench.py's roofline figures use SURVEY 8(d)'s per-unit work: F_hv = 4383 flop per
-    Hessian-vector product and 1496 B of HBM traffic per solve for LWA4D (N=18, k=3, 75 terms)."""
+    Hessian-vector product and 1512 B of HBM traffic per solve for LWA4D (N=18, k=3, 75 terms:
+    targets + Y_init in, Y_sol + the 48-byte gik_stats record out)."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location(
@@ -171,7 +172,7 @@ def test_bench_algorithmic_work_matches_survey():
     spec.loader.exec_module(bench)
     assert bench.algorithmic_flops(18, 3, 75, 1, 0, 0) == 4383
     assert bench.algorithmic_flops(13, 2, 19, 1, 0, 0) == 1116      # planar chain, C5
-    assert bench.algorithmic_bytes(18, 3, 75) == 8 * (75 + 2 * 54) + 32
+    assert bench.algorithmic_bytes(18, 3, 75) == 8 * (75 + 2 * 54) + 48 == 1512
 
 
 def test_problem_cache_key_follows_graph_content():
