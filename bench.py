@@ -69,7 +69,7 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
                     help="BASELINE.json workload (default c2 = configs[1], the bench line)")
     ap.add_argument("--robot", default=None,

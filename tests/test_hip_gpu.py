@@ -208,9 +208,8 @@ def test_finals_statistical_3d(torch_cuda, name, path):
     max |dq| < 1e-3 rad after wrapping).  Pointwise that bar only exists where the reference meets
     it against itself: its own two code paths (numpy closures vs costs.py loops, fixtures) end
     1e-2 rad apart on the 7-DOF arms, whose solution sets are self-motion curves.  So:
-      * on every goal where the reference's two paths agree to 1e-3, HIP agrees with it to 1e-3;
-      * UR10 (6 DOF, isolated solutions): every converged goal to 1e-3 (block path: 90 % to 1e-3,
-        all to 5e-3 -- one slowly converging goal, f = 1e-13, sits at 1.3e-3);
+      * UR10 (6 DOF, isolated solutions), pointwise: every converged goal to 1e-3 (block path: 90 %
+        to 1e-3, all to 5e-3 -- one slowly converging goal, f = 1e-13, sits at 1.3e-3);
       * the 7-DOF arms in distribution, MEDIAN against MEDIAN over all captured goals (the loop path
         is captured for every goal since round 3): median |dq| of HIP against the reference's numpy
         path no larger than 3x the larger of (the oracle's median |dq| against it, the median |dq|
@@ -246,18 +245,25 @@ def test_finals_statistical_3d(torch_cuda, name, path):
         "reference_np_vs_loops": dq_ref.tolist(), "hip_vs_reference_np": dq.tolist(),
         "oracle_vs_reference_np": dq_orc.tolist(), "converged": conv.astype(int).tolist(),
         "iterations_hip": its.tolist(), "iterations_reference": d["iterations"].tolist()})
-    for g in range(nl):
-        if dq_ref[g] < 1e-3:
-            assert dq[g] < 1e-3, (g, dq[g], dq_ref[g])
     if robot.n == 6:
+        # isolated solutions: pointwise.  Wherever the reference's two paths agree to 1e-3, so does HIP
+        for g in range(nl):
+            if dq_ref[g] < 1e-3 and conv[g]:
+                assert dq[g] < (1e-3 if path == "wave" else 5e-3), (g, dq[g], dq_ref[g])
         if path == "wave":
             assert np.all(dq[conv] < 1e-3), dq
         else:
             assert np.mean(dq[conv] < 1e-3) >= 0.9 and np.all(dq[conv] < 5e-3), dq
     else:
+        # 7-DOF arms: the solution set of a goal is a self-motion curve and where a solve stops on it
+        # is decided by round-off -- with every goal's loop path captured, the reference's own two
+        # paths are 3.4e-4 apart on a KUKA goal on which the oracle, restating the loop path line by
+        # line, ends 2.2e-2 away: no pointwise statement survives.  Median against median, and the
+        # upper quartile against the upper quartile:
         both = conv & (d["loop_f_sol"] < 1e-9)
-        bar = 3 * max(np.median(dq_orc[conv]), np.median(dq_ref[both]))
-        assert np.median(dq[conv]) <= bar, (np.median(dq[conv]), np.median(dq_orc[conv]), np.median(dq_ref[both]))
+        for qt in (50, 75):
+            bar = 3 * max(np.percentile(dq_orc[conv], qt), np.percentile(dq_ref[both], qt))
+            assert np.percentile(dq[conv], qt) <= bar, (qt, np.percentile(dq[conv], qt), bar)
         assert np.all((dq[conv] < 0.2) | (dq_orc[conv] > 0.05)), (dq, dq_orc)
 
 
@@ -1241,7 +1247,7 @@ def test_anchored_trajectory_against_oracle(torch_cuda):
     # the fixed-anchor problem is better conditioned than the quotient formulation (no gauge
     # freedom): the two renderings stay the same computation (decisions identical, f and |grad| to
     # 1e-8) well beyond the strict five iterations
-    assert np.median(k_hip) >= 8 and min(k_hip) >= 5, k_hip
+    assert np.median(k_hip) >= 12 and min(k_hip) >= 8, k_hip      # measured: 11 .. 32, median 21
 
 
 def test_anchored_pipeline(torch_cuda):
