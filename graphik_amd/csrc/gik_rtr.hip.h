@@ -68,6 +68,38 @@ __device__ inline double boundary_tau(double e_Pd2, double d_Pd, double Delta2, 
   return (sqrt(fma(e_Pd, e_Pd, d_Pd * (Delta2 - e_Pe))) - e_Pd) / d_Pd;   // no contraction left open
 }
 
+// Tail spreading (wavefront kernel, two waves per SIMD).  Once the queue of fresh problems is empty
+// the batch is a set of long-running problems scattered over the SIMDs: some SIMDs host two (each at
+// 0.5-0.7 of a lone wave's speed), others none.  A wave that runs out of work and finds its SIMD
+// empty becomes a HELPER: it reserves the SIMD (simd_run[sid] 0 -> 1), takes a hand-over ticket and
+// posts a credit.  A running wave polls the credits every fourth outer iteration; if there is one
+// and its own SIMD hosts two problems it takes the credit, pauses its solve -- a solve is exactly
+// resumable from (x, Delta, counters) -- publishes it under the next ticket and turns helper itself.
+// A SIMD's count only ever rises from 0 to 1 in this phase, so a problem moves at most once, and
+// every published problem has a helper waiting for exactly that ticket.  Results are bit-identical
+// to an unmigrated run (tests/test_full_size_gpu.py::test_tail_spreading_is_bit_identical).
+struct MigCtl {
+  int *credits;      // helpers waiting on an empty SIMD, not yet matched with a donor
+  int *simd_run;     // [MIG_SIMDS] problems running or reserved per physical SIMD
+  int sid;           // this wave's SIMD (XCC, SE, SH, CU, SIMD bits of the hardware id registers)
+};
+constexpr int MIG_SIMDS = 1 << 14;
+
+template <typename Ctx>
+__device__ inline bool mig_poll(const Ctx &cx, const MigCtl &m) {
+  int go = 0;
+  if (cx.lead()) {
+    if (__hip_atomic_load(m.credits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
+        __hip_atomic_load(&m.simd_run[m.sid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 2) {
+      if (__hip_atomic_fetch_add(m.credits, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 1)
+        go = 1;
+      else
+        __hip_atomic_fetch_add(m.credits, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(go) != 0;
+}
+
 // THETA_ONE: compiled for the reference default theta = 1 (trust_region.py:92), where
 // norm_r0 ** theta needs no pow().  The generic build evaluates pow() when theta != 1; inlined, its
 // polynomial constants are hoisted to the per-problem setup and spilled to scratch by every problem
@@ -75,10 +107,12 @@ __device__ inline double boundary_tau(double e_Pd2, double d_Pd, double Delta2, 
 // SLICE: compiled with the resume / pause hooks (workgroup-per-problem kernel).  The wave kernel
 // does without: the extra scalar state costs it its last free registers (256 VGPRs + scratch,
 // 972 -> 1114 cycles per iteration), more than time slicing returns there.
-template <int K, bool THETA_ONE, bool SLICE, typename Ctx>
+// MIG: SLICE with the pause decided by mig_poll() instead of a fixed slice length.
+template <int K, bool THETA_ONE, bool SLICE, typename Ctx, bool MIG = false>
 __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &trace, int has_trace,
                                      int dbg, double *dbg_buf, int b, double &x, RtrOut &out,
-                                     const RtrResume &rs, int slice_its) {
+                                     const RtrResume &rs, int slice_its, const MigCtl *mig = nullptr) {
+  static_assert(!MIG || SLICE, "tail spreading needs the resume / pause hooks");
   const double Delta_bar = 10.0 + K;  // typicaldist (fixed_rank_psd_sym.py:71-73)
   const bool lead = cx.lead();
     double Delta = (SLICE && rs.resumed) ? rs.Delta : Delta_bar / 8.0;   // trust_region.py:134-135,164
@@ -125,6 +159,13 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         if (kiter == 32) __builtin_amdgcn_s_setprio(1);
         else if (kiter == 128) __builtin_amdgcn_s_setprio(2);
         else if (kiter == 512) __builtin_amdgcn_s_setprio(3);
+        if constexpr (SLICE) {      // a resumed problem keeps the priority of its age
+          if (rs.resumed && slice_count == 0) {
+            if (kiter > 512) __builtin_amdgcn_s_setprio(3);
+            else if (kiter > 128) __builtin_amdgcn_s_setprio(2);
+            else if (kiter > 32) __builtin_amdgcn_s_setprio(1);
+          }
+        }
       }
       // -------------- _truncated_conjugate_gradient (trust_region.py:436-599) -------------
       const double Delta2 = Delta * Delta;
@@ -493,8 +534,12 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
       if (kiter >= p.maxiter) { stop = 1; break; }
       if (UNI(norm_grad < p.mingradnorm)) { stop = 0; break; }
       if (UNI(!(norm_grad == norm_grad) || !(fx == fx))) { bad = true; break; }
-      if constexpr (SLICE)
+      if constexpr (MIG) {
+        ++slice_count;
+        if ((kiter & 3) == 0 && mig_poll(cx, *mig)) { paused = true; break; }
+      } else if constexpr (SLICE) {
         if (slice_its > 0 && ++slice_count >= slice_its) { paused = true; break; }
+      }
     }
     if (bad) stop = 2;
     if constexpr (Ctx::AGE_PRIORITY) __builtin_amdgcn_s_setprio(0);

@@ -117,12 +117,49 @@ struct SolveArgs {
   // ticket B + t is the t-th re-queued problem, published in q_ids[t] / q_seq[t] (no slot is ever
   // reused: the ring has room for every possible re-queue of the launch).
   int slice_its;
+  // tail spreading (wavefront kernel, MIG variant): q_head = hand-over tickets taken by helpers,
+  // mig_credits / mig_simd_run as in MigCtl; q_tail / q_seq / q_ids / q_state / q_done as for slicing
+  unsigned int *q_head;
+  int *mig_credits, *mig_simd_run;
   unsigned int *q_tail, *q_done;   // next to work_counter (= the ticket counter)
   int *q_ids;                      // [cap]
   unsigned int *q_seq;             // [cap], 0xffffffff = not published
   SliceState *q_state;             // [B]
   BlockTabs bt;                    // workgroup-per-problem path
 };
+
+// This wave's physical SIMD: XCC_ID[3:0] and the SIMD / CU / SH / SE fields of HW_ID (bits 4-5 and
+// 8-15; the wave slot, pipe and queue fields in between and above say nothing about the place).
+__device__ inline int hw_simd_id() {
+  const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11));    // HW_REG_HW_ID[15:0]
+  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
+  return (int)(((hw >> 4) & 3u) | (((hw >> 8) & 0xffu) << 2) | (xcc << 10));
+}
+
+// Helper side of the tail spreading (MigCtl, gik_rtr.hip.h), one thread: wait until every problem is
+// done (-> -1) or a paused problem is handed to this wave (-> its index).  The wave first has to
+// find its SIMD empty and reserve it; while the SIMD is busy with the partner wave's problem it
+// polls slowly.
+__device__ inline int mig_wait(const MigCtl &m, unsigned int *q_head, const unsigned int *q_seq, const int *q_ids,
+                               const unsigned int *q_done, int B) {
+  for (;;) {
+    if (__hip_atomic_load(q_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)B) return -1;
+    int expect = 0;
+    if (__hip_atomic_load(&m.simd_run[m.sid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+        __hip_atomic_compare_exchange_strong(&m.simd_run[m.sid], &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT)) {
+      const unsigned int t = __hip_atomic_fetch_add(q_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(m.credits, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      for (;;) {
+        if (__hip_atomic_load(&q_seq[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)B + t)
+          return __hip_atomic_load(&q_ids[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(q_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)B) return -1;
+        __builtin_amdgcn_s_sleep(64);
+      }
+    }
+    for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);   // ~25 us
+  }
+}
 
 // Stage the launch-invariant slot table into LDS and zero the gather tiles (idle lanes and
 // padding slots read the never-written dump row, which must hold finite zeros).
@@ -140,9 +177,10 @@ __device__ inline void stage_lds(double *tiles, uint32_t *meta, const uint32_t *
 // XCDs idle behind a few stragglers; the queue keeps every SIMD busy until the end.
 // (the fixed-anchor variant holds 34 KB of LDS per wave: four waves per CU, one per SIMD, so it may
 // as well have that SIMD's whole register file -- at two waves per SIMD it spilled into the hot loop)
-template <int K, int MAXDEG, bool THETA_ONE, bool ANCH = false>
+template <int K, int MAXDEG, bool THETA_ONE, bool ANCH = false, bool MIG = false>
 __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs a) {
   static_assert(!ANCH || K == 3, "the fixed-anchor formulation is 3-D");
+  static_assert(!MIG || !ANCH, "tail spreading: two waves per SIMD, i.e. not the anchored variant");
   using Ctx = WaveCtx<K, MAXDEG, ANCH>;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
@@ -166,16 +204,40 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
   }
   const Params &p = a.p;
   int pass = 0;
+  MigCtl mig = {a.mig_credits, a.mig_simd_run, 0};
+  bool tail = false;
+  if constexpr (MIG) mig.sid = hw_simd_id();
   for (;;) {
-    int b = 0;
-    if (a.dbg & 1) {
-      b = (int)blockIdx.x + pass * (int)gridDim.x;
-      ++pass;
+    int b = 0, resumed = 0;
+    if constexpr (MIG) {
+      if (lane == 0) {
+        b = -1;
+        if (!tail) {
+          const unsigned int t = atomicAdd(a.work_counter, 1u);
+          if (t < (unsigned)a.B) {
+            b = (int)t;
+            __hip_atomic_fetch_add(&mig.simd_run[mig.sid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (b < 0) {
+          b = mig_wait(mig, a.q_head, a.q_seq, a.q_ids, a.q_done, a.B);
+          resumed = 1;
+        }
+      }
+      b = __builtin_amdgcn_readlane(b, 0);
+      resumed = __builtin_amdgcn_readlane(resumed, 0);
+      tail = tail || resumed;
+      if (UNI(b < 0)) break;
     } else {
-      if (lane == 0) b = (int)atomicAdd(a.work_counter, 1u);
-      b = __builtin_amdgcn_readlane(b, 0);  // lane 0 explicitly, independent of exec
+      if (a.dbg & 1) {
+        b = (int)blockIdx.x + pass * (int)gridDim.x;
+        ++pass;
+      } else {
+        if (lane == 0) b = (int)atomicAdd(a.work_counter, 1u);
+        b = __builtin_amdgcn_readlane(b, 0);  // lane 0 explicitly, independent of exec
+      }
+      if (UNI(b >= a.B)) break;
     }
-    if (UNI(b >= a.B)) break;
 
     if constexpr (ANCH) {
       if (lane < 3 * a.an.n_goal)
@@ -187,28 +249,59 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
       __builtin_amdgcn_wave_barrier();
       cx.load_slot_records();
     }
-    double x = cx.active ? a.Y_init[(size_t)b * NK + lane] : 0.0;
-
     RtrOut ro;
-    const RtrResume rs = {0.0, 0, 0, 0, 0, 0};
-    rtr_solve_one<K, THETA_ONE, false>(cx, p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro, rs, 0);
-    const double fx = ro.f, norm_grad = ro.gradnorm;
-    const int kiter = ro.iterations, inner_total = ro.inner_total, stop = ro.stop,
-              n_accept = ro.n_accept;
-
-    if (cx.active) a.Y_out[(size_t)b * NK + lane] = x;
+    double x;
+    if constexpr (MIG) {
+      RtrResume rs = {0.0, 0, 0, 0, 0, 0};
+      if (UNI(resumed)) {      // (state and point were written by a wave on another CU)
+        rs = load_slice_state(&a.q_state[b]);
+        x = cx.active ? __builtin_nontemporal_load(&a.Y_out[(size_t)b * NK + lane]) : 0.0;
+      } else {
+        x = cx.active ? a.Y_init[(size_t)b * NK + lane] : 0.0;
+      }
+      rtr_solve_one<K, THETA_ONE, true, Ctx, true>(cx, p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro, rs, 0,
+                                                   &mig);
+      if (cx.active) a.Y_out[(size_t)b * NK + lane] = x;
+      if (UNI(ro.paused)) {
+        if (lane == 0) {
+          SliceState st;
+          st.Delta = ro.Delta;
+          st.kiter = ro.iterations;
+          st.inner_total = ro.inner_total;
+          st.inner_exec = ro.inner_executed;
+          st.n_accept = ro.n_accept;
+          a.q_state[b] = st;
+        }
+        __threadfence();
+        if (lane == 0) {
+          requeue_work(a.q_tail, a.q_ids, a.q_seq, a.B, b);
+          __hip_atomic_fetch_add(&mig.simd_run[mig.sid], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        tail = true;
+        continue;
+      }
+    } else {
+      x = cx.active ? a.Y_init[(size_t)b * NK + lane] : 0.0;
+      const RtrResume rs = {0.0, 0, 0, 0, 0, 0};
+      rtr_solve_one<K, THETA_ONE, false>(cx, p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro, rs, 0);
+      if (cx.active) a.Y_out[(size_t)b * NK + lane] = x;
+    }
     if (lane == 0) {
       gik_stats s;
-      s.f = fx;
-      s.gradnorm = norm_grad;
-      s.iterations = kiter;
-      s.inner_total = inner_total;
-      s.stop = stop;
-      s.n_accept = n_accept;
+      s.f = ro.f;
+      s.gradnorm = ro.gradnorm;
+      s.iterations = ro.iterations;
+      s.inner_total = ro.inner_total;
+      s.stop = ro.stop;
+      s.n_accept = ro.n_accept;
       s.inner_executed = ro.inner_executed;
-      s.flags = 0;
+      s.flags = (MIG && resumed) ? 2 : 0;
       s.stepsize = ro.Delta;
       a.stats[b] = s;
+      if constexpr (MIG) {
+        __hip_atomic_fetch_add(&mig.simd_run[mig.sid], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.q_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
@@ -708,14 +801,19 @@ struct Variant {
   solve_fn solve_anch;   // fixed-anchor formulation (k = 3, theta == 1), or null
   kat_fn kat_anch;
   lds_fn lds_anch;
+  solve_fn solve_mig;    // theta == 1 with tail spreading (MigCtl), or null
 };
 #define GIK_VARIANT(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
-   lds_bytes_of<K, D>, nullptr, nullptr, nullptr}
+   lds_bytes_of<K, D>, nullptr, nullptr, nullptr, nullptr}
 #define GIK_VARIANT_A(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
-   lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>}
-static const Variant kVariants[] = {GIK_VARIANT_A(3, 9), GIK_VARIANT(3, 10), GIK_VARIANT_A(3, 20), GIK_VARIANT(2, 6),
+   lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, nullptr}
+#define GIK_VARIANT_AM(K, D) \
+  {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
+   lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, \
+   rtr_wave_kernel<K, D, true, false, true>}
+static const Variant kVariants[] = {GIK_VARIANT_AM(3, 9), GIK_VARIANT(3, 10), GIK_VARIANT_A(3, 20), GIK_VARIANT(2, 6),
                                     GIK_VARIANT(2, 16), GIK_VARIANT(2, 31)};
 
 }  // namespace gik
@@ -1644,14 +1742,21 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   const bool cg = t->solver == GIK_SOLVER_CONJUGATE_GRADIENT;
   if (!t->is_block || cg || B <= grid || (a.dbg & 1) || slice <= 0 || t->p.maxiter <= slice) slice = 0;
   a.slice_its = slice;
-  a.q_tail = a.q_done = nullptr;
+  a.q_tail = a.q_done = a.q_head = nullptr;
+  a.mig_credits = a.mig_simd_run = nullptr;
   a.q_ids = nullptr;
   a.q_seq = nullptr;
   a.q_state = nullptr;
+  // Tail spreading (wavefront kernel): only where two waves share a SIMD and the batch outlasts
+  // the queue -- more problems than resident waves -- and only on the tuned default variant
+  // (trust-region solver, theta = 1, not anchored).  debug_flags 512 turns it off (tests compare).
+  const bool mig = !t->is_block && !cg && !t->anchored && t->variant->solve_mig && t->p.theta == 1.0 &&
+                   wpc > 4 && B > grid && !(a.dbg & (1 | 512));
   gik_template::SliceWs *sw = nullptr;
-  if (slice > 0) {
-    const size_t cap = (size_t)B * (size_t)(t->p.maxiter / slice + 1);
-    const size_t off_seq = 16, off_ids = off_seq + cap * 4, off_state = (off_ids + cap * 4 + 15) & ~(size_t)15;
+  if (slice > 0 || mig) {
+    const size_t cap = mig ? (size_t)B + (size_t)grid + 64 : (size_t)B * (size_t)(t->p.maxiter / slice + 1);
+    const size_t off_simd = 16, off_seq = off_simd + (mig ? sizeof(int) * MIG_SIMDS : 0), off_ids = off_seq + cap * 4,
+                 off_state = (off_ids + cap * 4 + 15) & ~(size_t)15;
     const size_t bytes = off_state + (size_t)B * sizeof(SliceState);
     sw = &mt->slice_ws[mt->next_slice++ % gik_template::kSlicePool];
     if (!sw->done && hipEventCreateWithFlags(&sw->done, hipEventDisableTiming) != hipSuccess)
@@ -1669,10 +1774,13 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     char *base = static_cast<char *>(sw->base);
     a.q_tail = reinterpret_cast<unsigned int *>(base);
     a.q_done = a.q_tail + 1;
+    a.q_head = a.q_tail + 2;
+    a.mig_credits = reinterpret_cast<int *>(a.q_tail + 3);
+    a.mig_simd_run = reinterpret_cast<int *>(base + off_simd);
     a.q_seq = reinterpret_cast<unsigned int *>(base + off_seq);
     a.q_ids = reinterpret_cast<int *>(base + off_ids);
     a.q_state = reinterpret_cast<SliceState *>(base + off_state);
-    HIP_OK(hipMemsetAsync(base, 0, 16, (hipStream_t)stream));
+    HIP_OK(hipMemsetAsync(base, 0, off_seq, (hipStream_t)stream));
     HIP_OK(hipMemsetAsync(a.q_seq, 0xFF, cap * 4, (hipStream_t)stream));
   }
   if (t->is_block) {
@@ -1683,6 +1791,7 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   } else {
     hipLaunchKernelGGL(t->anchored ? t->variant->solve_anch
                        : cg        ? t->variant->solve_cg
+                       : mig       ? t->variant->solve_mig
                                    : (t->p.theta == 1.0 ? t->variant->solve : t->variant->solve_theta),
                        dim3(grid), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
   }

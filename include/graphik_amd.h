@@ -77,7 +77,9 @@ typedef struct {
                                 after a rejected step instead of resuming from the checkpoint;
                                 workgroup path: 64 = closed form for rigid cliques from 4 nodes
                                 up (default: 16 nodes); 128 / 256 = older spellings of
-                                clique_closed_form = GIK_CLIQUE_OFF / GIK_CLIQUE_DENSE          */
+                                clique_closed_form = GIK_CLIQUE_OFF / GIK_CLIQUE_DENSE; 512 = no tail
+                                spreading on the wavefront kernel (a scheduling measure of large
+                                batches, bit-neutral: tests compare both settings)                 */
   /* which of the reference's two solvers gik_solve_batch runs (riemannian_solver.py:40-65):
    * GIK_SOLVER_TRUST_REGIONS (default) or GIK_SOLVER_CONJUGATE_GRADIENT = pymanopt 0.2.5
    * ConjugateGradient + LineSearchAdaptive as configured at :51-59.  The CG defaults of
@@ -134,7 +136,9 @@ typedef struct {
                           bit for bit); inner_total counts what the reference would have run   */
   int32_t flags;       /* bit 0: workgroup kernels, rigid clique: the clique's target distances were
                           those of a point set in R^3 and its dense D w product was replaced by
-                          moments (informational; results agree to round-off either way)   */
+                          moments (informational; results agree to round-off either way);
+                          bit 1: wavefront kernel, tail of a large batch: the problem was paused and
+                          finished by a wave on another, idle SIMD (same result bit for bit)      */
   double stepsize;     /* ConjugateGradient: step of the last line search (the `stepsize` entry of
                           pymanopt's final_values); TrustRegions: trust-region radius at return  */
 } gik_stats;            /* 48 bytes                                                         */

@@ -145,6 +145,40 @@ def test_full_size_c5_planar(torch_cuda, name, B):
     assert np.mean((r["f"][:n] < 1e-9) == (o["f(x)"] < 1e-9)) > 0.97
 
 
+def test_tail_spreading_is_bit_identical(torch_cuda):
+    """Wavefront kernel, batches beyond the resident waves (two waves per SIMD): once the queue is
+    empty a wave whose SIMD hosts two long-running problems hands its problem -- (x, Delta,
+    counters), exactly resumable -- to a wave that waits on an empty SIMD.  Every output must equal
+    the run with debug_flags = 512 (no hand-overs) bit for bit, hand-overs must actually happen, and
+    a batch in which every problem is long (maxiter-bound start points) must terminate."""
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    robot, graph = make_graph("kuka")
+    rs = np.random.RandomState(0)
+    lb, ub = robot.limits_arrays()
+    Tg = robot.fk_batch(lb + (ub - lb) * rs.rand(65536, robot.n)[:8192])
+    keys = ("x", "f", "gradnorm", "iterations", "inner_total", "inner_executed", "stop", "n_accept", "stepsize")
+    out = {}
+    for name, params in (("spread", None), ("plain", {"debug_flags": 512})):
+        prob = BatchProblem(graph, use_limits=True, params=params)
+        tg, Y0 = prob.template.prepare(Tg)
+        r = prob.template.solve(Y0, tg)
+        torch_cuda.cuda.synchronize()
+        out[name] = {k: r[k].cpu().numpy() for k in keys + ("flags",)}
+    for k in keys:
+        assert np.array_equal(out["spread"][k], out["plain"][k], equal_nan=True), k
+    moved = (out["spread"]["flags"] & 2) != 0
+    assert moved.sum() >= 20 and not (out["plain"]["flags"] & 2).any(), moved.sum()
+    assert np.all(out["spread"]["iterations"][moved] > 200)        # only long problems move
+    # 4096 copies of three slow goals: nothing finishes early, every wave stays busy to the end
+    slow = np.argsort(-out["plain"]["iterations"])[:3]
+    prob = BatchProblem(graph, use_limits=True, params={"maxiter": 300})
+    tg, Y0 = prob.template.prepare(Tg[np.tile(slow, 1400)])
+    r = prob.template.solve(Y0, tg)
+    torch_cuda.cuda.synchronize()
+    x = r["x"].cpu().numpy().reshape(1400, 3, -1)
+    assert np.array_equal(x, np.broadcast_to(x[0], x.shape))
+
+
 # ---- concurrent batches on ONE handle (the "serving" figure of bench.py) ----------------------------
 def _serial_and_concurrent(torch, run, n_batches, n_streams):
     """run(i) issues batch i on torch's current stream and returns a dict of device tensors.
