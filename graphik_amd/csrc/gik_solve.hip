@@ -210,22 +210,31 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
   for (;;) {
     int b = 0, resumed = 0;
     if constexpr (MIG) {
-      if (lane == 0) {
-        b = -1;
-        if (!tail) {
-          const unsigned int t = atomicAdd(a.work_counter, 1u);
-          if (t < (unsigned)a.B) {
-            b = (int)t;
-            __hip_atomic_fetch_add(&mig.simd_run[mig.sid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (the static block -> problem alternative is never selected together with MIG on the host; it
+      // is what keeps the compiler's divergence analysis from treating this loop's exit as divergent
+      // and wrapping the solver loops in exec masks -- see the note at rcg_wave_kernel)
+      if (a.dbg & 1) {
+        b = (int)blockIdx.x + pass * (int)gridDim.x;
+        ++pass;
+        if (b >= a.B) b = -1;
+      } else {
+        if (lane == 0) {
+          b = -1;
+          if (!tail) {
+            const unsigned int t = atomicAdd(a.work_counter, 1u);
+            if (t < (unsigned)a.B) {
+              b = (int)t;
+              __hip_atomic_fetch_add(&mig.simd_run[mig.sid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          if (b < 0) {
+            b = mig_wait(mig, a.q_head, a.q_seq, a.q_ids, a.q_done, a.B);
+            resumed = 1;
           }
         }
-        if (b < 0) {
-          b = mig_wait(mig, a.q_head, a.q_seq, a.q_ids, a.q_done, a.B);
-          resumed = 1;
-        }
+        b = __builtin_amdgcn_readlane(b, 0);  // lane 0 explicitly, independent of exec
+        resumed = __builtin_amdgcn_readlane(resumed, 0);
       }
-      b = __builtin_amdgcn_readlane(b, 0);
-      resumed = __builtin_amdgcn_readlane(resumed, 0);
       tail = tail || resumed;
       if (UNI(b < 0)) break;
     } else {
@@ -252,13 +261,14 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
     RtrOut ro;
     double x;
     if constexpr (MIG) {
-      RtrResume rs = {0.0, 0, 0, 0, 0, 0};
-      if (UNI(resumed)) {      // (state and point were written by a wave on another CU)
-        rs = load_slice_state(&a.q_state[b]);
-        x = cx.active ? __builtin_nontemporal_load(&a.Y_out[(size_t)b * NK + lane]) : 0.0;
-      } else {
-        x = cx.active ? a.Y_init[(size_t)b * NK + lane] : 0.0;
-      }
+      // Branch-free on purpose: q_state is zeroed at launch, so a fresh problem reads zeros (a
+      // conditional load here made the compiler treat the solver's counters as divergent and wrap
+      // its loops in exec masks).  (State and point of a resumed problem were written by a wave on
+      // another CU: cache-bypassing loads.)
+      RtrResume rs = load_slice_state(&a.q_state[b]);
+      rs.resumed = resumed;
+      const double *src = resumed ? a.Y_out : a.Y_init;
+      x = cx.active ? __builtin_nontemporal_load(&src[(size_t)b * NK + lane]) : 0.0;
       rtr_solve_one<K, THETA_ONE, true, Ctx, true>(cx, p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro, rs, 0,
                                                    &mig);
       if (cx.active) a.Y_out[(size_t)b * NK + lane] = x;
@@ -1782,6 +1792,7 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     a.q_state = reinterpret_cast<SliceState *>(base + off_state);
     HIP_OK(hipMemsetAsync(base, 0, off_seq, (hipStream_t)stream));
     HIP_OK(hipMemsetAsync(a.q_seq, 0xFF, cap * 4, (hipStream_t)stream));
+    if (mig) HIP_OK(hipMemsetAsync(a.q_state, 0, (size_t)B * sizeof(SliceState), (hipStream_t)stream));
   }
   if (t->is_block) {
     void (*kern)(SolveArgs, int) =
