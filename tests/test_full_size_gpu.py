@@ -171,7 +171,6 @@ def test_tail_spreading_is_bit_identical(torch_cuda):
     assert np.array_equal(out["spread"]["inner_executed"][~moved], out["plain"]["inner_executed"][~moved])
     assert np.all(out["spread"]["inner_executed"][moved] >= out["plain"]["inner_executed"][moved])
     assert moved.sum() >= 20 and not (out["plain"]["flags"] & 2).any(), moved.sum()
-    assert np.all(out["spread"]["iterations"][moved] > 200)        # only long problems move
     # 4096 copies of three slow goals: nothing finishes early, every wave stays busy to the end
     slow = np.argsort(-out["plain"]["iterations"])[:3]
     prob = BatchProblem(graph, use_limits=True, params={"maxiter": 300})
