@@ -479,18 +479,22 @@ class Bench:
         out["gather"] = gather
         if serving is not None:
             out["serving"] = serving
-        traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if robot_name == "ur10_table" and not intended:
-            traffic_file = os.path.join(REPO, "profiles", "r02_block_hbm_traffic.json")
-        if os.path.exists(traffic_file) and ((robot_name == "lwa4d" and B == 4096) or
-                                             (robot_name == "ur10_table" and B == 4096 and not intended)):   # profiled workloads only
+        # HBM traffic of the solve kernel from the PMC passes of the SAME workload (tools/profile.sh:
+        # rocprofv3 cannot run inside this process), newest round first; null for unprofiled workloads
+        tags = {("lwa4d", 4096): ["r03", "r02"], ("ur10_table", 4096): ["r03_c3", "r02_block"],
+                ("kuka", 65536): ["r03_c4"], ("kuka", 8192): ["r03_c4share"], ("planar10", 65536): ["r03_c5", "r02_c5"]}
+        for tag in ([] if intended else tags.get((robot_name, B), [])):
+            traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json" if tag == "r02" else f"{tag}_hbm_traffic.json")
+            if not os.path.exists(traffic_file):
+                continue
             try:
                 tj = json.load(open(traffic_file))
                 out["roofline"]["traffic"] = tj.get("bytes_per_launch")
                 out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(traffic_file)}: rocprofv3 --pmc "
-                                                     "passes of this command in a separate run "
+                                                     "passes of this workload in a separate run "
                                                      "(tools/profile.sh + tools/summarize_prof.py), not "
                                                      "measured by the process that printed this line")
+                break
             except Exception:
                 pass
 
@@ -525,7 +529,7 @@ def brief(o):
             "goals_total": o["config"]["goals_total"], "batch_per_gpu": o["config"]["batch_per_gpu"],
             "kernel": r["kernel"], "kernel_ms": r["kernel_ms"],
             "roofline": {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
-                         "frac": r["frac"], "frac_executed": r["frac_executed"]},
+                         "frac": r["frac"], "frac_executed": r["frac_executed"], "traffic": r["traffic"]},
             "success_rate": o["success_rate"], "frac_maxiter": o["frac_maxiter"],
             "median_pos_err_m": o["median_pos_err_m"], "median_rot_err_rad": o["median_rot_err_rad"],
             "outer_iterations": o["outer_iterations"],

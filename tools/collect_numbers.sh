@@ -7,7 +7,7 @@ python bench.py --config c3 --intended > gpurun_out/final/bench_c3_intended.json
 python bench.py --config c4 --steps 3 --no-cpu-baseline > gpurun_out/final/bench_c4_n1.json 2>/dev/null
 python bench.py --config c5 --steps 3 --no-cpu-baseline > gpurun_out/final/bench_c5_n1.json 2>/dev/null
 for cfg in "lwa4d 16384" "kuka 4096" "kuka 8192" "ur10 4096" "planar10 4096" "planar10 8192" "planar10_halfpi 4096"; do set -- $cfg; python bench.py --robot $1 --batch $2 --steps 3 --no-cpu-baseline > gpurun_out/final/bench_$1_$2.json 2>/dev/null; done
-python -u tools/dev_single_goal.py > gpurun_out/final/single_goal.txt 2>&1
+python -u tools/attic/dev_single_goal.py > gpurun_out/final/single_goal.txt 2>&1
 for f in gpurun_out/final/bench_*.json; do python - $f <<'PY'
 import json,sys
 try:

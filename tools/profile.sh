@@ -5,11 +5,11 @@
 # Results land under gpurun_out/prof_<tag>/; tools/summarize_prof.py copies the summaries worth keeping
 # to profiles/.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r02}; shift
+TAG=${1:-r03}; shift
 P=$R/gpurun_out/prof_$TAG
 mkdir -p "$P"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --serving-streams 0 $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --serving-streams 0 --headline-only $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt -o r1 -- python $R/bench.py $ARGS > $P/kt_bench.json 2> $P/kt.err
 for set in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \

@@ -7,7 +7,8 @@ kept under profiles/ (run here after gpurun merged gpurun_out/prof back).
 Writes
     profiles/<tag>_kernel_stats.csv     per-kernel durations (copy of rocprofv3 --stats)
     profiles/<tag>_pmc_per_launch.json  every collected counter, mean per dispatch and kernel
-    profiles/hbm_traffic.json           HBM bytes per launch of the solve kernel (bench.py reads it)
+    profiles/<tag>_hbm_traffic.json     HBM bytes per launch of the solve kernel (bench.py reads the
+                                        newest one of the profiled workload)
     profiles/<tag>_bench_n1.json        the bench line of the profiled command
 Counter handling follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are collected in
 separate --pmc passes, are in KiB, and FETCH_SIZE counts half the bytes on gfx950 (x2).
@@ -21,7 +22,7 @@ import sys
 from collections import defaultdict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 P = os.path.join(REPO, "gpurun_out", "prof_" + tag)
 out = os.path.join(REPO, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -56,7 +57,7 @@ json.dump({"kernel": solve, "bytes_per_launch": fetch + write, "fetch_bytes_corr
                   "tools/profile.sh %s), bench.py --steps 2 --warmup 1, mean over the dispatches; " % tag +
                   "FETCH_SIZE (KiB) x1024 x2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM "
                   "section), WRITE_SIZE (KiB) x1024"},
-          open(os.path.join(out, "hbm_traffic.json" if tag == "r02" else f"{tag}_hbm_traffic.json"), "w"), indent=1)
+          open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 
 for line in open(os.path.join(P, "kt_bench.json")):
     if line.startswith("{"):
