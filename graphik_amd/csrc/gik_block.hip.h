@@ -46,6 +46,7 @@ constexpr int CLQ_NMOM = 27;              // Sw[3], M[3][3], T3[3], U3[3] (Eucli
 struct BlockTabs {
   const int *nc_term;      // [Tc] index in the caller's target row of each slot-table term; null = identity
   const int *clq_term;     // [M][512] target index of clique pair (row tid >> 2, row 4m + (tid & 3)); -1 = none
+  const int *clq_term_t;   // [512][CLQ_M] the same table transposed: thread tid's row is one 128-byte line
   const int *node_of_row;  // [128] node (the caller's numbering) of each LDS row; null = identity
   const int *wave_sl;      // [8][2] slot-loop bounds {SLE, SL} of each wavefront
   int Tc;                  // terms kept in the slot tables
@@ -71,7 +72,16 @@ struct BlockCtx {
   int n_clq, M_clq;
   bool wclq;                   // this wavefront owns clique rows (wave-uniform)
   uint32_t clq_valid;          // bit m: (node, 4m + part) is a clique pair
-  double Dr[CLQ_M];            // its squared target distance
+  // its squared target distance is NOT kept in registers (28 + 4 doubles per thread used to sit
+  // there for the whole solve and were spilled around proj_setup: 4.4 GB of scratch traffic per
+  // 4096-goal launch): the once-per-outer-iteration walks of cost() / commit() read it from the
+  // problem's target row in global memory (45 KB, L2-resident), dr(m)
+  const double *tg_clq;        // this problem's targets [T] (global)
+  const int *clq_row;          // BlockTabs::clq_term_t + tid * CLQ_M: this thread's 128-byte row of indices
+  __device__ inline double dr(int m) const {
+    const int idx = clq_row[m];
+    return (idx >= 0 && tg_clq) ? tg_clq[idx] : 0.0;
+  }
   double rD, n_count;          // sum_j D_ij of the node; (double)n_clq
   double yt[3], ytp, y2t;      // centred row of the node, own entry, squared norm
   // Euclidean targets: if the clique's D_ij are the squared distances of points X_j in R^3 (any
@@ -135,10 +145,8 @@ struct BlockCtx {
     lowrank = false;
     rr = 0.0;
     Xr[0] = Xr[1] = Xr[2] = 0.0;
-    if constexpr (K == 3) {
-#pragma unroll
-      for (int m = 0; m < CLQ_M; ++m) Dr[m] = 0.0;
-    }
+    tg_clq = nullptr;
+    clq_row = bt.clq_term_t ? bt.clq_term_t + (size_t)tid * CLQ_M : nullptr;
   }
 
   // per problem: the slot-table targets into LDS (sh_tgt, writable alias `tgw`), the clique's
@@ -150,13 +158,13 @@ struct BlockCtx {
       if (n_clq) {
         double s = 0.0;
         uint32_t v = 0u;
+        tg_clq = tg_b;
 #pragma unroll
         for (int m = 0; m < CLQ_M; ++m) {
           if (m >= M_clq) continue;
-          const int idx = bt.clq_term[m * BLOCK_NT + tid];
-          Dr[m] = (idx >= 0 && tg_b) ? tg_b[idx] : 0.0;
+          const int idx = clq_row[m];
           v |= (idx >= 0 ? 1u : 0u) << m;
-          s += Dr[m];
+          s += (idx >= 0 && tg_b) ? tg_b[idx] : 0.0;
         }
         clq_valid = v;
         s += dpp_f64<0xB1>(s);
@@ -240,7 +248,7 @@ struct BlockCtx {
       double r[K];
       row(pb, 4 * m, r);
       const double e0 = Xr[0] - r[0], e1 = Xr[1] - r[1], e2 = Xr[2] - r[2];
-      const double e = fma(e2, e2, fma(e1, e1, e0 * e0)) - Dr[m];
+      const double e = fma(e2, e2, fma(e1, e1, e0 * e0)) - dr(m);
       bad += (((clq_valid >> m) & 1u) && !(fabs(e) <= tol)) ? 1.0 : 0.0;
       if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
@@ -359,7 +367,7 @@ struct BlockCtx {
             const double y = own[q] - r[q];
             d = fma(y, y, d);
           }
-          const double u = Dr[m] - d;
+          const double u = dr(m) - d;
           const bool mine = ((clq_valid >> m) & 1u) && (4 * m + part > node);
           f = fma(mine ? u : 0.0, u, f);
           if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight (registers)
@@ -423,7 +431,7 @@ struct BlockCtx {
             y[q] = own[q] - r[q];
             d = fma(y[q], y[q], d);
           }
-          const double c = ((clq_valid >> m) & 1u) ? d - Dr[m] : 0.0;
+          const double c = ((clq_valid >> m) & 1u) ? d - dr(m) : 0.0;
 #pragma unroll
           for (int q = 0; q < K; ++q) acc[q] = fma(c, y[q], acc[q]);
           if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -535,13 +543,15 @@ struct BlockCtx {
 #pragma unroll
     for (int g = 0; g < CLQ_M / 4; ++g) {
       if (4 * g >= M_clq) continue;
-      double buf[4][K];
+      double buf[4][K], dg[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dg[u] = dr(4 * g + u);
 #pragma unroll
       for (int u = 0; u < 4; ++u) row(wb, 4 * (4 * g + u), buf[u]);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
 #pragma unroll
-        for (int q = 0; q < K; ++q) acc[q] = fma(Dr[4 * g + u], buf[u][q], acc[q]);
+        for (int q = 0; q < K; ++q) acc[q] = fma(dg[u], buf[u][q], acc[q]);
       }
       __builtin_amdgcn_sched_barrier(0);   // do not hoist later groups' loads (registers)
     }

@@ -879,7 +879,7 @@ struct gik_template {
   bool is_block;  // workgroup-per-problem path
   int SL;         // slots per thread on the block path
   int SLE;        // ... of which the first SLE hold equality terms (or padding) only
-  gik::BlockTabs bt = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+  gik::BlockTabs bt = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
   // device pre/post-processing (gik_pipeline_attach)
   bool has_pipe;
   gik::PipeConst pc;
@@ -1307,6 +1307,13 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     bool ok = true;
     t->bt.nc_term = upload(t, nc_term.data(), nc_term.size(), ok);
     t->bt.clq_term = upload(t, clq_term.data(), clq_term.size(), ok);
+    {   // the same table, one 128-byte row per thread (BlockCtx::dr)
+      std::vector<int> tt((size_t)BLOCK_NT * CLQ_M, -1);
+      const size_t Mrows = clq_term.size() / BLOCK_NT;
+      for (size_t m = 0; m < Mrows && m < (size_t)CLQ_M; ++m)
+        for (int tid = 0; tid < BLOCK_NT; ++tid) tt[(size_t)tid * CLQ_M + m] = clq_term[m * BLOCK_NT + tid];
+      t->bt.clq_term_t = upload(t, tt.data(), tt.size(), ok);
+    }
     t->bt.node_of_row = upload(t, node_of_row.data(), node_of_row.size(), ok);
     t->bt.wave_sl = upload(t, wave_sl.data(), wave_sl.size(), ok);
     t->bt.Tc = Tc;
