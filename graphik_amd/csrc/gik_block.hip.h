@@ -46,7 +46,9 @@ constexpr int CLQ_NMOM = 27;              // Sw[3], M[3][3], T3[3], U3[3] (Eucli
 struct BlockTabs {
   const int *nc_term;      // [Tc] index in the caller's target row of each slot-table term; null = identity
   const int *clq_term;     // [M][512] target index of clique pair (row tid >> 2, row 4m + (tid & 3)); -1 = none
-  const int *clq_term_t;   // [512][CLQ_M] the same table transposed: thread tid's row is one 128-byte line
+  const int *clq_pair_term;        // [n_pairs] target index of clique pair p (each pair once)
+  const unsigned short *clq_pid_t; // [M][512] pair id of (row tid >> 2, row 4m + (tid & 3)), like clq_term; 0xffff = none
+  int n_pairs;
   const int *node_of_row;  // [128] node (the caller's numbering) of each LDS row; null = identity
   const int *wave_sl;      // [8][2] slot-loop bounds {SLE, SL} of each wavefront
   int Tc;                  // terms kept in the slot tables
@@ -74,13 +76,15 @@ struct BlockCtx {
   uint32_t clq_valid;          // bit m: (node, 4m + part) is a clique pair
   // its squared target distance is NOT kept in registers (28 + 4 doubles per thread used to sit
   // there for the whole solve and were spilled around proj_setup: 4.4 GB of scratch traffic per
-  // 4096-goal launch): the once-per-outer-iteration walks of cost() / commit() read it from the
-  // problem's target row in global memory (45 KB, L2-resident), dr(m)
-  const double *tg_clq;        // this problem's targets [T] (global)
-  const int *clq_row;          // BlockTabs::clq_term_t + tid * CLQ_M: this thread's 128-byte row of indices
+  // 4096-goal launch).  The clique's targets -- each pair once, 44.5 KB on the table scene -- are
+  // staged in LDS per problem (sh_ctg), the pair ids of a thread's partners once per kernel
+  // (sh_pid, 16 bit): the once-per-outer-iteration walks of cost() / commit() gather from there.
+  double *sh_ctg;              // [n_pairs] squared target distances of the clique pairs
+  const unsigned short *sh_pid;// [CLQ_M rows used][512] pair id of (node, 4m + part), 0xffff = none
   __device__ inline double dr(int m) const {
-    const int idx = clq_row[m];
-    return (idx >= 0 && tg_clq) ? tg_clq[idx] : 0.0;
+    if (m >= M_clq) return 0.0;       // (the dense D w product runs whole groups of four partners)
+    const unsigned p = sh_pid[m * BLOCK_NT + tid];
+    return p != 0xffffu ? sh_ctg[p] : 0.0;
   }
   double rD, n_count;          // sum_j D_ij of the node; (double)n_clq
   double yt[3], ytp, y2t;      // centred row of the node, own entry, squared norm
@@ -104,10 +108,11 @@ struct BlockCtx {
   double *prof = nullptr;
 #endif
 
-  __host__ __device__ static constexpr size_t lds_bytes(int T, int SL) {
+  __host__ __device__ static constexpr size_t lds_bytes(int T, int SL, int n_pairs = 0, int n_clq = 0) {
     return sizeof(double) * ((size_t)3 * BLOCK_MAXN * RS + (size_t)((T + 1) & ~1) + 2 * 8 * BLOCK_WAVES +
                              CLQ_NMOM * BLOCK_WAVES + CLQ_NCQ + 32 * BLOCK_WAVES) +
-           sizeof(uint32_t) * (size_t)SL * BLOCK_NT + (HAS_CK ? sizeof(double) * 4 * BLOCK_NT : 0);
+           sizeof(uint32_t) * (size_t)SL * BLOCK_NT + (HAS_CK ? sizeof(double) * 4 * BLOCK_NT : 0) +
+           sizeof(double) * (size_t)((n_pairs + 1) & ~1) + sizeof(unsigned short) * (size_t)((n_clq + 3) / 4) * BLOCK_NT;
   }
 
   __device__ inline bool lead() const { return tid == 0; }
@@ -145,8 +150,8 @@ struct BlockCtx {
     lowrank = false;
     rr = 0.0;
     Xr[0] = Xr[1] = Xr[2] = 0.0;
-    tg_clq = nullptr;
-    clq_row = bt.clq_term_t ? bt.clq_term_t + (size_t)tid * CLQ_M : nullptr;
+    sh_ctg = sh_ck + (HAS_CK ? 4 * BLOCK_NT : 0);
+    sh_pid = reinterpret_cast<const unsigned short *>(sh_ctg + ((bt.n_pairs + 1) & ~1));
   }
 
   // per problem: the slot-table targets into LDS (sh_tgt, writable alias `tgw`), the clique's
@@ -158,13 +163,14 @@ struct BlockCtx {
       if (n_clq) {
         double s = 0.0;
         uint32_t v = 0u;
-        tg_clq = tg_b;
+        for (int p = tid; p < bt.n_pairs; p += BLOCK_NT) sh_ctg[p] = tg_b ? tg_b[bt.clq_pair_term[p]] : 0.0;
+        __syncthreads();
 #pragma unroll
         for (int m = 0; m < CLQ_M; ++m) {
           if (m >= M_clq) continue;
-          const int idx = clq_row[m];
-          v |= (idx >= 0 ? 1u : 0u) << m;
-          s += (idx >= 0 && tg_b) ? tg_b[idx] : 0.0;
+          const unsigned p = sh_pid[m * BLOCK_NT + tid];
+          v |= (p != 0xffffu ? 1u : 0u) << m;
+          s += dr(m);
         }
         clq_valid = v;
         s += dpp_f64<0xB1>(s);

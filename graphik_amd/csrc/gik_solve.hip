@@ -450,6 +450,10 @@ __device__ inline uint32_t *block_stage(BlockCtx<K> &cx, double *smem, const uin
                                    32 * BLOCK_WAVES);
   for (int s = 0; s < SL; ++s) slots[s * BLOCK_NT + tid] = g_slots[s * BLOCK_NT + tid];
   cx.init(N, SL, bt, smem, slots, T);
+  if constexpr (K == 3) {   // pair ids of every thread's clique partners (launch invariant)
+    unsigned short *pid = const_cast<unsigned short *>(cx.sh_pid);
+    for (int m = 0; m < cx.M_clq; ++m) pid[m * BLOCK_NT + tid] = bt.clq_pid_t[m * BLOCK_NT + tid];
+  }
   __syncthreads();
   return slots;
 }
@@ -879,7 +883,7 @@ struct gik_template {
   bool is_block;  // workgroup-per-problem path
   int SL;         // slots per thread on the block path
   int SLE;        // ... of which the first SLE hold equality terms (or padding) only
-  gik::BlockTabs bt = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+  gik::BlockTabs bt = {nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0};
   // device pre/post-processing (gik_pipeline_attach)
   bool has_pipe;
   gik::PipeConst pc;
@@ -1041,7 +1045,8 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   if (is_block && ad) return fail("anchored templates need N * k <= 64 free unknowns and at most 20 terms per node");
   // workgroup-per-problem tables (BlockTabs)
   int n_clq = 0, Tc = T;
-  std::vector<int> nc_term, clq_term, node_of_row(BLOCK_MAXN, -1), wave_sl(2 * BLOCK_WAVES, 0);
+  std::vector<int> nc_term, clq_term, clq_pair_term, node_of_row(BLOCK_MAXN, -1), wave_sl(2 * BLOCK_WAVES, 0);
+  std::vector<unsigned short> clq_pid;   // [M][512] compact pair id per (thread, partner), 0xffff = none
   if (is_block) {
     // A rigid clique -- a set of nodes every pair of which is tied by an equality term (the
     // anchors of a scene with many obstacles) -- is taken out of the slot tables and handled in
@@ -1106,6 +1111,21 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
         const int j = 4 * m + part;
         if (j < n_clq && j != row)
           clq_term[(size_t)m * BLOCK_NT + tid] = eqterm[(size_t)node_of_row[row] * N + node_of_row[j]];
+      }
+    }
+    // each clique pair once (its target is staged in LDS per problem) + the pair id of every
+    // (thread, partner): ids fit 16 bits (at most 128 * 127 / 2 pairs)
+    {
+      std::vector<int> pid_of_term((size_t)T, -1);
+      clq_pid.assign((size_t)std::max(M, 1) * BLOCK_NT, (unsigned short)0xffff);
+      for (size_t q = 0; q < clq_term.size(); ++q) {
+        const int term = clq_term[q];
+        if (term < 0) continue;
+        if (pid_of_term[term] < 0) {
+          pid_of_term[term] = (int)clq_pair_term.size();
+          clq_pair_term.push_back(term);
+        }
+        clq_pid[q] = (unsigned short)pid_of_term[term];
       }
     }
     // four threads per node; a node's equality terms are dealt to them in turn, then its hinge
@@ -1212,7 +1232,8 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   t->next_counter = 0;
   t->counter_slot.resize(kCounterRing);
   t->has_pipe = false;
-  t->smem_bytes = is_block ? (d->k == 3 ? BlockCtx<3>::lds_bytes(Tc, SL) : BlockCtx<2>::lds_bytes(Tc, SL))
+  t->smem_bytes = is_block ? (d->k == 3 ? BlockCtx<3>::lds_bytes(Tc, SL, (int)clq_pair_term.size(), n_clq)
+                                        : BlockCtx<2>::lds_bytes(Tc, SL))
                            : (ad ? var->lds_anch(T) : var->lds(T));
   if (is_block && t->smem_bytes > 160 * 1024) {
     delete t;
@@ -1307,13 +1328,9 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     bool ok = true;
     t->bt.nc_term = upload(t, nc_term.data(), nc_term.size(), ok);
     t->bt.clq_term = upload(t, clq_term.data(), clq_term.size(), ok);
-    {   // the same table, one 128-byte row per thread (BlockCtx::dr)
-      std::vector<int> tt((size_t)BLOCK_NT * CLQ_M, -1);
-      const size_t Mrows = clq_term.size() / BLOCK_NT;
-      for (size_t m = 0; m < Mrows && m < (size_t)CLQ_M; ++m)
-        for (int tid = 0; tid < BLOCK_NT; ++tid) tt[(size_t)tid * CLQ_M + m] = clq_term[m * BLOCK_NT + tid];
-      t->bt.clq_term_t = upload(t, tt.data(), tt.size(), ok);
-    }
+    t->bt.clq_pair_term = upload(t, clq_pair_term.data(), clq_pair_term.size(), ok);
+    t->bt.clq_pid_t = upload(t, clq_pid.data(), clq_pid.size(), ok);
+    t->bt.n_pairs = (int)clq_pair_term.size();
     t->bt.node_of_row = upload(t, node_of_row.data(), node_of_row.size(), ok);
     t->bt.wave_sl = upload(t, wave_sl.data(), wave_sl.size(), ok);
     t->bt.Tc = Tc;
