@@ -203,7 +203,7 @@ def cpu_baseline(prob, T_goal, Y0_h, B, args):
 
 
 def executed_flops(N, k, T, info, lowrank_frac, n_inner, n_outer, n_accept):
-    """Flops the solve kernel EXECUTES.  Wavefront kernel: the algorithmic count
+    """Flops the solve kernel EXECUTES (NOTEBOOK 4.1).  Wavefront kernel: the algorithmic count
     (every term is evaluated once per product).  Workgroup kernel with a rigid clique of n nodes
     in closed form: per Hessian product the T_rest terms left in the per-term loops (12 k each),
     the moments (18, or 27 with Euclidean targets: one multiply + one add per clique node each),
@@ -470,7 +470,7 @@ class Bench:
                                     "flop count of SURVEY 8(d) (12 k |E| per product); a rigid anchor clique "
                                     "is evaluated in closed form with far fewer operations -- "
                                     "`frac_executed` prices the flops the kernel actually executes "
-                                    "(bench.py: executed_flops, DESIGN 4.1)")},
+                                    "(bench.py: executed_flops, DESIGN 4.2)")},
             "roofline_hbm": {"bound": "hbm", "achieved": hbm_bytes / (kernel_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -1474,7 +1474,7 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   } else {
     // the prepare kernel is latency-bound (dependent Jacobi chains, LDS round trips): run as many
     // resident waves per CU as its registers and LDS allow (a fixed 8 per CU left half of them
-    // unused: planar-10 prepare 2.3 -> see DESIGN 4.2)
+    // unused: planar-10 prepare 2.3 -> see NOTEBOOK 4.2)
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prep_wave_kernel, WAVE, t->prep_smem) != hipSuccess)
       occ = 8;

@@ -301,7 +301,7 @@ def test_effort_parity_ur10(torch_cuda):
     tCG solve runs into maxinner (the reference's never do; a search direction that keeps the
     vertical round-off of the gradient does, late in a solve, in one solve out of five), outer
     iterations agree in distribution and the Hessian products stay within 12 % of the oracle's
-    (measured +8 %: the column-form product puts its round-off outside range(J^T); the
+    (measured +8 %: the column-form product puts its round-off outside range(J^T), NOTEBOOK 2; the
     bound was 15 % in round 2)."""
     from oracle import c_oracle as co
     from graphik_amd.solvers.riemannian_solver import BatchProblem
