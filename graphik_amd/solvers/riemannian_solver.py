@@ -189,6 +189,7 @@ class BatchProblem:
         else:
             self.psi_L = self.psi_U = None
         self.N = N
+        self.terms = build_terms(self.omega, self.psi_L, self.psi_U, use_limits)   # (i, j, kind, static target)
         if host_only:
             self.template, self.device_pipeline = None, False
             return
@@ -326,7 +327,17 @@ class BatchProblem:
         else:
             with ThreadPoolExecutor(workers) as ex:
                 Ys = list(ex.map(one, spans))
-        return self.template.targets_from_D(D), np.concatenate(Ys, axis=0)
+        return self.targets_from_D(D), np.concatenate(Ys, axis=0)
+
+    def targets_from_D(self, D):
+        """[B,N,N] squared-distance matrices -> [B,T] per-term targets (Template.targets_from_D without
+        a device handle)."""
+        ti, tj, tk, tv = self.terms
+        D = np.asarray(D, dtype=np.float64)
+        tg = D[:, ti, tj].copy()
+        hinge = tk != 1
+        tg[:, hinge] = tv[hinge]
+        return tg
 
     def joint_variables(self, Y, T_goals):
         from ..graphs.graph_revolute import joint_variables_revolute_batch
