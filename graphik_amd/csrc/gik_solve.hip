@@ -827,8 +827,16 @@ struct Variant {
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
    lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, \
    rtr_wave_kernel<K, D, true, false, true>}
-static const Variant kVariants[] = {GIK_VARIANT_AM(3, 9), GIK_VARIANT(3, 10), GIK_VARIANT_A(3, 20), GIK_VARIANT(2, 6),
-                                    GIK_VARIANT(2, 16), GIK_VARIANT(2, 31)};
+// anchored templates only: the free-free formulation with more than 10 terms at a node runs on the
+// workgroup kernels (the 20-slot wavefront variant needed 796 B of scratch per lane: measured on the
+// two-end-effector tree of tests/golden/tree5.npz, 13 terms, 144 k against 382 k solves/s;
+// tools/gpu_variants.py.  <3,10> 48 B: -1.3 % against <3,9>; <2,16> 168 B: 5x faster than the
+// workgroup kernels on the planar trees -- both stay)
+#define GIK_VARIANT_ANCH_ONLY(K, D) \
+  {K, D, nullptr, nullptr, nullptr, nullptr, lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, \
+   kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, nullptr}
+static const Variant kVariants[] = {GIK_VARIANT_AM(3, 9), GIK_VARIANT(3, 10), GIK_VARIANT_ANCH_ONLY(3, 20),
+                                    GIK_VARIANT(2, 6), GIK_VARIANT(2, 16), GIK_VARIANT(2, 31)};
 
 }  // namespace gik
 
@@ -1038,7 +1046,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   std::vector<uint32_t> meta;
   if (!is_block) {   // smallest compiled slot count that holds the busiest node
     for (const Variant &v : kVariants)
-      if (v.K == d->k && v.maxdeg >= maxdeg && (!var || v.maxdeg < var->maxdeg) && (!ad || v.solve_anch))
+      if (v.K == d->k && v.maxdeg >= maxdeg && (!var || v.maxdeg < var->maxdeg) && (ad ? v.solve_anch != nullptr : v.solve != nullptr))
         var = &v;
     if (!var) is_block = true;   // a node busier than any wave variant: workgroup-per-problem path
   }

@@ -153,7 +153,8 @@ class Template:
         _ffi.check(self.lib.gik_template_get_info(self._h, C.byref(info)))
         self.info = {f: getattr(info, f) for f, _ in _ffi.TemplateInfo._fields_ if f != "reserved"}
         deg = np.bincount(np.concatenate([self.term_i, self.term_j]), minlength=self.N).max()
-        self.maxdeg = next((m for m in ((9, 10, 20) if self.k == 3 else (6, 16, 31)) if m >= deg), int(deg))
+        sizes = (9, 10, 20) if (self.k == 3 and self.anchored) else ((9, 10) if self.k == 3 else (6, 16, 31))
+        self.maxdeg = next((m for m in sizes if m >= deg), int(deg))     # compiled slot count (or the raw degree: workgroup path)
 
     @classmethod
     def from_matrices(cls, omega, psi_L=None, psi_U=None, k=3, use_limits=True, **kw):

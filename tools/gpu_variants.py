@@ -47,4 +47,5 @@ ti, tj, tk, tv = build_terms(prob.omega, prob.psi_L, prob.psi_U, True)
 deg = np.bincount(np.concatenate([ti, tj]), minlength=prob.N)
 i = int(np.argmax(deg)); j = next(j for j in range(prob.N) if j != i and prob.omega[i, j] == 0 and prob.psi_L[i, j] == 0 and prob.psi_U[i, j] == 0)
 prob.psi_U = prob.psi_U.copy(); prob.psi_U[i, j] = prob.psi_U[j, i] = 100.0     # an upper hinge that never binds
+prob.terms = build_terms(prob.omega, prob.psi_L, prob.psi_U, True)
 bench("lwa4d + 1 inert hinge (10)", prob, Tg, B)
