@@ -796,6 +796,11 @@ def test_block_path_known_answers(torch_cuda, name, flags):
 
 @pytest.mark.parametrize("name,flags", [("lwa4d", 0), ("lwa4d", 64), ("ur10", 64), ("planar10_limits_halfpi", 0)])
 def test_block_path_trajectories_match_wave_path(torch_cuda, name, flags):
+    """The two kernel paths sum the same terms in different orders, so on 3-D goals they part where
+    round-off is amplified to 1e-8 -- like any two renderings of the algorithm (stable_prefix).  Strict:
+    decisions identical and f to 1e-7 for 5 (3-D) / 8 (planar) outer iterations on every goal; and the
+    iteration at which each goal's traces really part (decisions or f, |grad| at 1e-8) is reported and
+    bounded from below in the median."""
     from graphik_amd.engine import Template
     d = load_golden(name)
     use_lim = bool(int(d["use_limits"]))
@@ -804,8 +809,9 @@ def test_block_path_trajectories_match_wave_path(torch_cuda, name, flags):
     Tb = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"],
                                 params={"force_block_path": 1, "debug_flags": flags}, **kw)
     tg = Tw.targets_from_D(d["D_goal"])
-    rw = Tw.solve(d["Y_init"], tg, trace_cap=16)
-    rb = Tb.solve(d["Y_init"], tg, trace_cap=16)
+    from parity_util import first_divergence, report
+    rw = Tw.solve(d["Y_init"], tg, trace_cap=32)
+    rb = Tb.solve(d["Y_init"], tg, trace_cap=32)
     m = 5 if int(d["dim"]) == 3 else 8
     for key in ("numit", "stop", "accept", "Delta"):
         assert np.array_equal(rw["trace"][key].cpu().numpy()[:, :m], rb["trace"][key].cpu().numpy()[:, :m])
@@ -813,6 +819,13 @@ def test_block_path_trajectories_match_wave_path(torch_cuda, name, flags):
                        rb["trace"]["f_before"].cpu().numpy()[:, :m], rtol=1e-7)
     fw, fb = rw["f"].cpu().numpy(), rb["f"].cpu().numpy()
     assert np.array_equal(fw < 1e-9, fb < 1e-9)
+    tw = {k: v.cpu().numpy() for k, v in rw["trace"].items()}
+    tb = {k: v.cpu().numpy() for k, v in rb["trace"].items()}
+    iw, ib = rw["iterations"].cpu().numpy(), rb["iterations"].cpu().numpy()
+    part = [first_divergence({k: tw[k][g] for k in tw}, {k: tb[k][g] for k in tb}, min(32, int(iw[g]), int(ib[g])))
+            for g in range(len(iw))]
+    report(f"trajectory_prefix/{name}/block_vs_wave/flags{flags}", {"paths_part_at": part})
+    assert min(part) >= m and np.median(part) >= (m + 2 if int(d["dim"]) == 3 else m), part
 
 
 def test_clique_closed_form_against_direct_sum(torch_cuda):
