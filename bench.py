@@ -163,7 +163,7 @@ def dry_results(T_goal):
 
 def cpu_baseline(prob, T_goal, Y0_h, B, args):
     """The oracle (C restatement, -O3 AVX2+FMA, OpenMP over problems) timed on this host: one
-    thread on a small sample and every usable core on >= 32 goals per thread (capped at the batch).
+    thread on a small sample and every usable core on 64 goals per thread (capped at the batch).
     Hessian products per second per thread are tail-free and are what to compare machines by."""
     from oracle import c_oracle as co
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -187,7 +187,7 @@ def cpu_baseline(prob, T_goal, Y0_h, B, args):
     big = prob.N * prob.dim > 64            # table scene: ~1 s per solve per thread
     n1 = min(B, 2 if big else 24)
     t1, hv1 = run(n1, 1)
-    ns = args.cpu_sample or min(B, 2 * cores if big else max(64, 32 * cores))
+    ns = args.cpu_sample or min(B, 2 * cores if big else max(64, 64 * cores))   # ~15 s of CPU work
     tc, hvc = run(ns, cores)
     return {
         "value": ns / tc, "unit": "solves/s", "cores": cores, "kind": "port",
