@@ -335,3 +335,12 @@ def test_rccl_gather_under_torchrun(torch_cuda):
     # strong-scaling workload through the same path (c5: cheap)
     c = _bench(launcher, "--backend", "nccl", "--config", "c5")
     assert c["gather"]["rows"] == 65536 and c["scaling"] == "strong" and c["success_rate"] > 0.99
+    # the driver's own invocation (no --config) under the launcher: the headline plus every other
+    # BASELINE workload under "configs", all through the same process group
+    d = _bench(launcher, "--backend", "nccl")
+    assert d["config"]["config"] == "c2" and d["gather"]["backend"] == "nccl" and d["gather"]["rows"] == 4096
+    assert set(d["configs"]) == {"c3", "c4", "c4_share_of_8", "c5"}
+    for name, lo in (("c3", 1000), ("c4", 80e3), ("c4_share_of_8", 35e3), ("c5", 5e6)):
+        cf = d["configs"][name]
+        assert cf["value"] > lo and 0 < cf["roofline"]["frac_executed"] <= cf["roofline"]["frac"] < 1, (name, cf)
+    assert d["configs"]["c3"]["success_rate"] > 0.88 and d["configs"]["c5"]["success_rate"] > 0.999
