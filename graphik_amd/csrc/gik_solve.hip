@@ -866,6 +866,7 @@ struct gik_template {
   };
   std::vector<CounterSlot> counter_slot;   // [kCounterRing]
   unsigned next_counter = 0;
+  int counter_ring = 256;   // slots in use (GIK_COUNTER_RING at creation: tests shrink it to force wraps)
   std::mutex call_mutex;    // counter ring + time-slicing pool: held from slot hand-out to event record
   std::mutex ev_mutex;      // ev_solve0 / ev_solve1 (anchored templates)
   int clique_mode = 0;      // gik_template_desc::clique_closed_form as resolved at creation
@@ -877,9 +878,10 @@ struct gik_template {
     hipEvent_t done = nullptr;
     bool pending = false;
   };
-  static constexpr int kSlicePool = 8;
+  static constexpr int kSlicePool = 32;
   SliceWs slice_ws[kSlicePool];
   unsigned next_slice = 0;
+  int slice_pool = kSlicePool;   // slots in use (GIK_SLICE_POOL at creation: tests shrink it to force reuse)
   int device;
   int n_cu;
   // scheduling knobs, fixed at creation (descriptor fields, overridden once by the environment)
@@ -907,7 +909,6 @@ struct gik_template {
   int sweeps;
 };
 static constexpr int kCounterRing = 256;
-static int g_counter_ring = kCounterRing;   // GIK_COUNTER_RING (tests: a tiny ring must still be safe)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a launch: several
 // templates share a kernel, so the allowance is only ever raised (a later, smaller template must
@@ -1015,7 +1016,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   if (d->cg_beta_type < 0 || d->cg_beta_type > 3) return fail("cg_beta_type must be 0..3");
   if (d->clique_closed_form < GIK_CLIQUE_AUTO || d->clique_closed_form > GIK_CLIQUE_DENSE)
     return fail("clique_closed_form must be GIK_CLIQUE_AUTO, _OFF or _DENSE");
-  if (const char *e = getenv("GIK_COUNTER_RING")) g_counter_ring = std::min(kCounterRing, std::max(1, atoi(e)));
+
   bool is_block = d->N * d->k > WAVE || d->N > 32 || d->force_block_path != 0;
   if (d->N < 2 || d->N > BLOCK_MAXN) return fail("N must be in [2, 128]");
   if (d->n_terms < 1 || d->n_terms > 65535) return fail("n_terms out of range");
@@ -1239,6 +1240,9 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   t->d_counters = nullptr;
   t->next_counter = 0;
   t->counter_slot.resize(kCounterRing);
+  t->counter_ring = kCounterRing;
+  if (const char *e = getenv("GIK_COUNTER_RING")) t->counter_ring = std::min(kCounterRing, std::max(1, atoi(e)));
+  if (const char *e = getenv("GIK_SLICE_POOL")) t->slice_pool = std::min(gik_template::kSlicePool, std::max(1, atoi(e)));
   t->has_pipe = false;
   t->smem_bytes = is_block ? (d->k == 3 ? BlockCtx<3>::lds_bytes(Tc, SL, (int)clq_pair_term.size(), n_clq)
                                         : BlockCtx<2>::lds_bytes(Tc, SL))
@@ -1757,7 +1761,7 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   // concurrent calls on one handle (any number of host threads and streams) are safe.
   gik_template *mt = const_cast<gik_template *>(t);
   std::lock_guard<std::mutex> call_lock(mt->call_mutex);
-  gik_template::CounterSlot &cs = mt->counter_slot[mt->next_counter++ % (unsigned)g_counter_ring];
+  gik_template::CounterSlot &cs = mt->counter_slot[mt->next_counter++ % (unsigned)t->counter_ring];
   a.work_counter = t->d_counters + (&cs - mt->counter_slot.data());
   if (!cs.done && hipEventCreateWithFlags(&cs.done, hipEventDisableTiming) != hipSuccess)
     return fail("hipEventCreate failed");
@@ -1800,7 +1804,7 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     const size_t off_simd = 16, off_seq = off_simd + (mig ? sizeof(int) * MIG_SIMDS : 0), off_ids = off_seq + cap * 4,
                  off_state = (off_ids + cap * 4 + 15) & ~(size_t)15;
     const size_t bytes = off_state + (size_t)B * sizeof(SliceState);
-    sw = &mt->slice_ws[mt->next_slice++ % gik_template::kSlicePool];
+    sw = &mt->slice_ws[mt->next_slice++ % (unsigned)t->slice_pool];
     if (!sw->done && hipEventCreateWithFlags(&sw->done, hipEventDisableTiming) != hipSuccess)
       return fail("hipEventCreate failed");
     if (sw->bytes < bytes) {

@@ -228,16 +228,19 @@ def test_concurrent_batches_wave_path(torch_cuda):
     _serial_and_concurrent(torch, run, 16, 8)
 
 
-def test_concurrent_batches_block_path_with_time_slicing(torch_cuda):
+def test_concurrent_batches_block_path_with_time_slicing(torch_cuda, monkeypatch):
     """Workgroup-per-problem kernels on one handle from 8 streams: the solve kernel with time slicing
-    (more problems than resident workgroups: re-queue rings from the handle's pool of 8, so 16
-    launches in flight make the pool wrap) and the workgroup-per-goal prepare kernel (launches share
-    one scratch slab and are chained by an event)."""
+    (more problems than resident workgroups: re-queue rings from the handle's pool of workspaces,
+    shrunk to 4 here -- GIK_SLICE_POOL, read at create -- so that 24 launches in flight reuse every
+    slot several times behind its event) and the workgroup-per-goal prepare kernel (launches share one
+    scratch slab and are chained by an event)."""
     torch = torch_cuda
     from graphik_amd.solvers.riemannian_solver import BatchProblem
     robot, graph = make_graph("lwa4d")
+    monkeypatch.setenv("GIK_SLICE_POOL", "4")
     prob = BatchProblem(graph, use_limits=True, force_block_prepare=True,
                         params={"force_block_path": 1, "slice_outer_its": 24})
+    monkeypatch.delenv("GIK_SLICE_POOL")
     tpl = prob.template
     assert tpl.info["is_block"] == 1
     B = tpl.info["n_cu"] * tpl.info["waves_per_cu"] + 192        # more than fit at once -> slicing on
