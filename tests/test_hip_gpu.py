@@ -822,10 +822,12 @@ def test_block_path_trajectories_match_wave_path(torch_cuda, name, flags):
     tw = {k: v.cpu().numpy() for k, v in rw["trace"].items()}
     tb = {k: v.cpu().numpy() for k, v in rb["trace"].items()}
     iw, ib = rw["iterations"].cpu().numpy(), rb["iterations"].cpu().numpy()
-    part = [first_divergence({k: tw[k][g] for k in tw}, {k: tb[k][g] for k in tb}, min(32, int(iw[g]), int(ib[g])))
-            for g in range(len(iw))]
-    report(f"trajectory_prefix/{name}/block_vs_wave/flags{flags}", {"paths_part_at": part})
-    assert min(part) >= m and np.median(part) >= (m + 2 if int(d["dim"]) == 3 else m), part
+    n = [min(32, int(iw[g]), int(ib[g])) for g in range(len(iw))]      # (planar solves end after 7-13 iterations)
+    part = [first_divergence({k: tw[k][g] for k in tw}, {k: tb[k][g] for k in tb}, n[g]) for g in range(len(iw))]
+    report(f"trajectory_prefix/{name}/block_vs_wave/flags{flags}", {"paths_part_at": part, "compared": n})
+    assert all(p >= min(m, q) for p, q in zip(part, n)), (part, n)
+    if int(d["dim"]) == 3:
+        assert np.median(part) >= m + 2, part
 
 
 def test_clique_closed_form_against_direct_sum(torch_cuda):
