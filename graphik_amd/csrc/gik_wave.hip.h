@@ -36,12 +36,9 @@ constexpr int WAVE = 64;
 constexpr int TILE_ROWS = 33;  // 32 nodes max + one dump row for idle lanes
 
 // slot metadata word: [7:0] neighbour node j, [23:8] term index, [25:24] kind, [26] owner
-// bits 27..31 (wavefront path): position of node j in the product's gather buffer (hv_pos, below)
-__host__ __device__ inline uint32_t meta_pack(int j, int term, int kind, int owner, int hvpos = 0) {
-  return (uint32_t)j | ((uint32_t)term << 8) | ((uint32_t)kind << 24) | ((uint32_t)owner << 26) |
-         ((uint32_t)hvpos << 27);
+__host__ __device__ inline uint32_t meta_pack(int j, int term, int kind, int owner) {
+  return (uint32_t)j | ((uint32_t)term << 8) | ((uint32_t)kind << 24) | ((uint32_t)owner << 26);
 }
-__host__ __device__ inline int meta_hvpos(uint32_t m) { return (int)(m >> 27); }
 __host__ __device__ inline int meta_j(uint32_t m) { return (int)(m & 0xffu); }
 __device__ inline int meta_term(uint32_t m) { return (int)((m >> 8) & 0xffffu); }
 __device__ inline int meta_kind(uint32_t m) { return (int)((m >> 24) & 3u); }
@@ -349,8 +346,8 @@ struct WaveCtx {
   static constexpr bool AGE_PRIORITY = true;   // waves of different problems share a SIMD (rtr_solve_one)
   __host__ __device__ static constexpr size_t lds_bytes(int T) {
     return sizeof(double) * ((size_t)K * TILE + (size_t)((T + 1) & ~1)) +
-           sizeof(uint32_t) * (size_t)(MAXDEG + 1) * WAVE + sizeof(SlotRec) * (size_t)MAXDEG * WAVE +
-           sizeof(double) * WAVE + (HAS_CK ? sizeof(double) * 4 * WAVE : 0) +
+           sizeof(uint32_t) * (size_t)MAXDEG * WAVE + sizeof(SlotRec) * (size_t)MAXDEG * WAVE +
+           (HAS_CK ? sizeof(double) * 4 * WAVE : 0) +
            (ANCH ? sizeof(double) * 4 * (ANCH_MAXA + ANCH_MAXOBS) + 16 * (size_t)ANCH_PMAX * WAVE +
                        48 * (size_t)WAVE : 0);
   }
@@ -389,7 +386,7 @@ struct WaveCtx {
   ObsState *sh_ost;        // [64]
   bool obs_cull;
   __device__ inline void init_anchored(const uint64_t obs_mask, const double *obs, int n_obs_, bool cull) {
-    sh_anch = sh_ck + (HAS_CK ? 4 * WAVE : 0);
+    sh_anch = sh_ck + 4 * WAVE;
     sh_obs = sh_anch + 4 * ANCH_MAXA;
     sh_prec = reinterpret_cast<PinRec *>(sh_obs + 4 * ANCH_MAXOBS);
     sh_ost = reinterpret_cast<ObsState *>(sh_prec + ANCH_PMAX * WAVE);
@@ -467,7 +464,7 @@ struct WaveCtx {
     y[K - 1] = comp == 0 ? yn[2] : (comp == 1 ? yn[0] : yn[1]);
   }
   __device__ static inline SlotRec *rec_base(uint32_t *meta) {
-    return reinterpret_cast<SlotRec *>(meta + (MAXDEG + 1) * WAVE);
+    return reinterpret_cast<SlotRec *>(meta + MAXDEG * WAVE);
   }
   __device__ inline void ck_put(int i, double v) { sh_ck[i * WAVE + lane] = v; }
   __device__ inline double ck_get(int i) const { return sh_ck[i * WAVE + lane]; }
@@ -485,29 +482,15 @@ struct WaveCtx {
 
   double *sh_tile;         // K rotated tiles
   const double *sh_tgt;    // [T] per-problem residual targets
-  const uint32_t *sh_meta; // [MAXDEG + 1][64]: slot words; row MAXDEG = the lane's own gather-buffer position
+  const uint32_t *sh_meta; // [MAXDEG][64]
   SlotRec *sh_rec;         // [MAXDEG][64]
   double *sh_ck;           // [4][64] tCG checkpoint (own lane only: no barrier needed)
-  // (where this lane's value goes in tile t, and its node's row in its own tile, are recomputed from
-  // nat_off / comp / tile_base where they are needed -- once per outer iteration -- instead of
-  // living in registers through the tCG loop)
-  __device__ inline int waddr(int t) const { return t * TILE + nat_off + (comp - t + (comp < t ? K : 0)); }
-  __device__ inline int own_off() const { return tile_base + nat_off; }
+  int waddr[K];            // where this lane's value goes in tile 0..K-1 (double index)
+  int own_off;             // this lane's node row in its own tile (double index)
   int nat_off;             // this lane's node row in tile 0 (natural component order)
-  // Gather buffer of the Hessian product: the direction vector, one double per unknown, node j at
-  // doubles K * hv_pos(j) .. + K - 1 of a 64-double strip of its own.  The positions are chosen at
-  // template creation (gik_template_create: hv_positions) so that the MAXDEG ds_read_b64 gathers and
-  // the ds_write_b64 of an iteration hit as few LDS bank pairs twice as the graph allows (the
-  // natural-order 48-byte rows of tile 0 cost 30 LDS cycles for LWA4D's nine gathers, the chosen
-  // layout 22, the minimum is 18); entry 63 (62 for K = 2) is never written and reads as zero for
-  // idle lanes.  Same values, same arithmetic: results do not depend on the layout.
-  double *sh_hv;           // [64]
-  int hvoff[MAXDEG];       // entry of (neighbour j, this lane's component) in sh_hv
-  int hv_w;                // this lane's own entry
-  int tile_base;           // comp * TILE: row of node j in this lane's rotated tile = j * RS + tile_base
-  __device__ inline int rowoff(int s) const {
-    return meta_j(sh_meta[s * WAVE + lane]) * RS + tile_base;
-  }
+  int coloff[MAXDEG];      // neighbour entry (j, comp) in tile 0 (double index)
+  int tile_delta;          // row of node j in this lane's rotated tile = coloff + tile_delta
+  __device__ inline int rowoff(int s) const { return coloff[s] + tile_delta; }
   // Row of the 3x3 (2x2) Hessian block of slot s that belongs to this lane's component, rotated
   // like the tiles:  bq[s][q] = 2 a y_c y_(c+q) + c_ij [q == 0].   bsum = sum_s bq[s].
   double bq[MAXDEG][K];
@@ -529,14 +512,14 @@ struct WaveCtx {
   __device__ inline void put(double v) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int t = 0; t < K; ++t) sh_tile[waddr(t)] = v;
+    for (int t = 0; t < K; ++t) sh_tile[waddr[t]] = v;
     __builtin_amdgcn_wave_barrier();
   }
 
-  // publish a vector in the gather buffer (all the column-form Hessian product reads)
+  // publish only the natural-order tile (all the column-form Hessian product reads)
   __device__ inline void put1(double v) {
     __builtin_amdgcn_wave_barrier();
-    sh_hv[hv_w] = v;
+    sh_tile[waddr[0]] = v;
     __builtin_amdgcn_wave_barrier();
   }
 
@@ -560,20 +543,24 @@ struct WaveCtx {
                               uint32_t *meta) {
     lane = lane_;
     sh_rec = rec_base(meta);
-    sh_hv = reinterpret_cast<double *>(sh_rec + MAXDEG * WAVE);
-    sh_ck = sh_hv + WAVE;
+    sh_ck = reinterpret_cast<double *>(sh_rec + MAXDEG * WAVE);
     active = lane < N * K;
     node = active ? lane / K : (TILE_ROWS - 1);
     comp = active ? lane - node * K : 0;
     sh_tile = tiles;
     sh_tgt = tgt;
     sh_meta = meta;
-    tile_base = comp * TILE;       // (tile t stores component (t + pos) % K of a row at pos: waddr())
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      const int pos = (comp - t + K) % K;  // tile t stores component (t + pos) % K at pos
+      waddr[t] = t * TILE + node * RS + pos;
+    }
+    own_off = comp * TILE + node * RS;
+    tile_delta = comp * TILE - comp;
     nat_off = node * RS;
-    hv_w = K * (int)sh_meta[MAXDEG * WAVE + lane] + comp;
 #pragma unroll
     for (int s = 0; s < MAXDEG; ++s) {
-      hvoff[s] = K * meta_hvpos(sh_meta[s * WAVE + lane]) + comp;
+      coloff[s] = meta_j(sh_meta[s * WAVE + lane]) * RS + comp;
 #pragma unroll
       for (int q = 0; q < K; ++q) bq[s][q] = 0.0;
     }
@@ -585,7 +572,7 @@ struct WaveCtx {
   // is counted exactly twice and the total is halved (exact).
   __device__ inline double cost(double Yv) {
     put(Yv);
-    const Row<K> own = read_row(own_off());
+    const Row<K> own = read_row(own_off);
     double f = 0.0;
 #pragma unroll
     for (int s = 0; s < MAXDEG; ++s) {
@@ -648,7 +635,7 @@ struct WaveCtx {
   // Refresh the per-slot constants at the point whose rows are in the LDS tiles and return this
   // lane's entry of egrad (lgrad / jgrad, costs.py:98-123, 20-35): G_i = 2 sum_j c_ij (Y_i-Y_j).
   __device__ inline double commit() {
-    const Row<K> own = read_row(own_off());
+    const Row<K> own = read_row(own_off);
     double G = 0.0;
 #pragma unroll
     for (int s = 0; s < MAXDEG; ++s) {
@@ -779,7 +766,7 @@ struct WaveCtx {
     put1(W);
     double ww[MAXDEG];
 #pragma unroll
-    for (int s = 0; s < MAXDEG; ++s) ww[s] = sh_hv[hvoff[s]];
+    for (int s = 0; s < MAXDEG; ++s) ww[s] = sh_tile[coloff[s]];
     __builtin_amdgcn_sched_barrier(0);
     double p[K];
 #pragma unroll
