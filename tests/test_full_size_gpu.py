@@ -347,3 +347,26 @@ def test_rccl_gather_under_torchrun(torch_cuda):
         cf = d["configs"][name]
         assert cf["value"] > lo and 0 < cf["roofline"]["frac_executed"] <= cf["roofline"]["frac"] < 1, (name, cf)
     assert d["configs"]["c3"]["success_rate"] > 0.88 and d["configs"]["c5"]["success_rate"] > 0.999
+
+
+def test_integration_stub_runs(torch_cuda):
+    """The ctypes stub INTEGRATION.md tells a GraphIK maintainer to add is executed as written (only
+    the library path is filled in) and must give, bit for bit, what the package's own engine gives."""
+    import re
+    from conftest import load_golden
+    from graphik_amd import _ffi
+    from graphik_amd.engine import Template
+    md = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    block = next(b for b in re.findall(r"```python\n(.*?)```", md, flags=re.S) if "hip_backend.py" in b)
+    block = block.replace('C.CDLL("libgraphik_amd.so")', f'C.CDLL({_ffi.LIB_PATH!r})')
+    ns = {}
+    exec(compile(block, "INTEGRATION.md:hip_backend", "exec"), ns)
+    d = load_golden("lwa4d")
+    stub = ns["HipTemplate"](d["omega"], d["psi_L"], d["psi_U"], 3, use_limits=True)
+    Y, stats = stub.solve(d["Y_init"], d["D_goal"])
+    torch_cuda.cuda.synchronize()
+    T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=3, use_limits=True)
+    r = T.solve(d["Y_init"], T.targets_from_D(d["D_goal"]))
+    assert np.array_equal(Y.cpu().numpy(), r["x"].cpu().numpy())
+    assert np.array_equal(stats[:, 0].cpu().numpy(), r["f"].cpu().numpy())
+    assert np.array_equal(stats.view(torch_cuda.int32)[:, 4].cpu().numpy(), r["iterations"].cpu().numpy())
