@@ -1422,3 +1422,16 @@ def test_planar_tree_solve_batch(torch_cuda, which):
     q_sol, Y1 = solve_with_riemannian(graph, T_goal)
     for ee in robot.end_effectors:
         assert np.linalg.norm(robot.pose(q_sol, ee).trans - T_goal[ee].trans) < 1e-3
+    # against the reference's own solves of the same trees (RiemannianSolver.solve from its Y_init,
+    # tests/golden/planar_tree.npz): same iteration count, same point, same angles
+    from graphik_amd.solvers.riemannian_solver import RiemannianSolver
+    d = load_golden("planar_tree")
+    g = lambda k: d[f"{which}_{k}"]   # noqa: E731
+    solver = RiemannianSolver(graph)
+    for s_ in range(len(g("sol_f"))):
+        info = solver.solve(g("D_goal")[s_], g("omega"), use_limits=True, Y_init=g("sol_Y_init")[s_], jit=False)
+        assert info["iterations"] == int(g("sol_iterations")[s_]) and info["f(x)"] < 1e-20
+        assert np.abs(info["x"] - g("sol_Y_sol")[s_]).max() < 1e-9
+        q = graph.joint_variables(info["x"])
+        dq = np.array([q[j] for j in robot.joint_ids[1:]]) - g("sol_q_sol")[s_]
+        assert np.abs(np.mod(dq + np.pi, 2 * np.pi) - np.pi).max() < 1e-8

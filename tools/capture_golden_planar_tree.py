@@ -27,10 +27,17 @@ import refcompat  # noqa: E402
 import numpy as np  # noqa: E402
 import networkx as nx  # noqa: E402
 
+refcompat.patch_skew()
+import graphik.solvers.riemannian_solver as rs  # noqa: E402
+import graphik.solvers.costs as costs  # noqa: E402
+from graphik.solvers.riemannian_solver import RiemannianSolver  # noqa: E402
 from graphik.robots import RobotPlanar  # noqa: E402
 from graphik.graphs import ProblemGraphPlanar  # noqa: E402
 from graphik.utils.dgp import (adjacency_matrix_from_graph, bound_smoothing,  # noqa: E402
-                               distance_matrix_from_graph, pos_from_graph)
+                               distance_matrix_from_graph, graph_from_pos, pos_from_graph)
+
+for _n in ("jcost", "jgrad", "jhess", "lcost", "lgrad", "lhess"):
+    setattr(rs, _n, getattr(costs, _n))
 from graphik.utils.utils import list_to_variable_dict  # noqa: E402
 from graphik.utils.constants import DIST, LOWER, UPPER, BOUNDED, BELOW  # noqa: E402
 
@@ -106,6 +113,24 @@ if __name__ == "__main__":
             LB.append(lb); UB.append(ub)
         o.update(q_goal=np.array(Q), q_rec=np.array(QR), X=np.array(X), T_goal=np.array(TG),
                  D_goal=np.array(DG), lb=np.array(LB), ub=np.array(UB))
+        # full solves through RiemannianSolver.solve (the reference has no solve_with_riemannian for
+        # trees): initial point, solution, cost, iteration count, recovered angles, worst EE error
+        sol = {k: [] for k in ("Y_init", "Y_sol", "f", "iterations", "q_sol", "pos_err")}
+        psi_L, psi_U = o["psi_L"], o["psi_U"]
+        for g in range(4):
+            q = {j: Q[g][i] for i, j in enumerate(robot.joint_ids[1:])}
+            T_goal = {ee: robot.pose(q, ee) for ee in robot.end_effectors}
+            Gd = graph.from_pose(T_goal)
+            Y_init = RiemannianSolver.generate_initialization((LB[g], UB[g]), 2, o["omega"], psi_L, psi_U)
+            info = RiemannianSolver(graph).solve(DG[g], o["omega"], use_limits=True, Y_init=Y_init.copy(), jit=False)
+            q_sol = graph.joint_variables(graph_from_pos(info["x"], ids))
+            err = max(np.linalg.norm(robot.pose(q_sol, ee).trans - T_goal[ee].trans) for ee in robot.end_effectors)
+            print(f"  {which} goal {g}: it={info['iterations']} f={info['f(x)']:.2e} pos_err={err:.2e}", flush=True)
+            for k, v in (("Y_init", Y_init), ("Y_sol", info["x"]), ("f", info["f(x)"]),
+                         ("iterations", info["iterations"]), ("q_sol", [q_sol[j] for j in robot.joint_ids[1:]]),
+                         ("pos_err", err)):
+                sol[k].append(v)
+        o.update({"sol_" + k: np.array(v) for k, v in sol.items()})
         out.update({f"{which}_{k}": v for k, v in o.items()})
         print(which, "nodes", ids, "ee", robot.end_effectors, "joints", robot.joint_ids)
     path = os.path.join(REPO, "tests", "golden", "planar_tree.npz")
