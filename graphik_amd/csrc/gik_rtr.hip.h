@@ -78,11 +78,21 @@ __device__ inline double boundary_tau(double e_Pd2, double d_Pd, double Delta2, 
 // A SIMD's count only ever rises from 0 to 1 in this phase, so a problem moves at most once, and
 // every published problem has a helper waiting for exactly that ticket.  Results are bit-identical
 // to an unmigrated run (tests/test_full_size_gpu.py::test_tail_spreading_is_bit_identical).
+// Round-robin time slicing rides on the same hooks: after `slice_its` outer iterations a problem
+// yields its slot if anything is waiting (an unclaimed fresh problem or an earlier yielder), so that
+// the long problems -- unknown in advance -- are not the last to START; the yielder queues behind
+// everything that waits (MigCtl::wait_*: fresh ticket counter / yield queue head and tail).
 struct MigCtl {
   int *credits;      // helpers waiting on an empty SIMD, not yet matched with a donor
   int *simd_run;     // [MIG_SIMDS] problems running or reserved per physical SIMD
   int sid;           // this wave's SIMD (XCC, SE, SH, CU, SIMD bits of the hardware id registers)
+  const unsigned int *fresh;    // ticket counter of the fresh problems (tickets < B)
+  const unsigned int *y_head;   // yield queue: entries claimed ...
+  const unsigned int *y_tail;   // ... and published
+  int B;
+  unsigned int y_cap;           // entries of the yield queue (no yield once it is nearly full)
 };
+enum { PAUSE_NONE = 0, PAUSE_DONATE = 1, PAUSE_YIELD = 2 };
 constexpr int MIG_SIMDS = 1 << 14;
 
 template <typename Ctx>
@@ -98,6 +108,19 @@ __device__ inline bool mig_poll(const Ctx &cx, const MigCtl &m) {
     }
   }
   return __builtin_amdgcn_readfirstlane(go) != 0;
+}
+
+// is anything waiting for a slot?  (one thread's loads, broadcast)
+template <typename Ctx>
+__device__ inline bool mig_anyone_waiting(const Ctx &cx, const MigCtl &m) {
+  int w = 0;
+  if (cx.lead()) {
+    const unsigned int yt = __hip_atomic_load(m.y_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w = yt + 4096u < m.y_cap &&
+        (__hip_atomic_load(m.fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)m.B ||
+         __hip_atomic_load(m.y_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < yt);
+  }
+  return __builtin_amdgcn_readfirstlane(w) != 0;
 }
 
 // THETA_ONE: compiled for the reference default theta = 1 (trust_region.py:92), where
@@ -125,7 +148,7 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
     int kiter = SLICE ? rs.kiter : 0, inner_total = SLICE ? rs.inner_total : 0,
         inner_exec = SLICE ? rs.inner_exec : 0, n_accept = SLICE ? rs.n_accept : 0, stop = 1;
     int slice_count = 0;
-    bool paused = false;
+    int paused = PAUSE_NONE;
     // ---- Retrace (k = 3 wave path) --------------------------------------------------------
     // A rejected step leaves x, g and the Hessian unchanged and divides the radius by 4
     // (:336-338, :382), so the reference's next tCG solve repeats the previous one operation for
@@ -536,9 +559,13 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
       if (UNI(!(norm_grad == norm_grad) || !(fx == fx))) { bad = true; break; }
       if constexpr (MIG) {
         ++slice_count;
-        if ((kiter & 3) == 0 && mig_poll(cx, *mig)) { paused = true; break; }
+        if ((kiter & 3) == 0 && mig_poll(cx, *mig)) { paused = PAUSE_DONATE; break; }
+        if (slice_its > 0 && slice_count >= slice_its) {
+          if (mig_anyone_waiting(cx, *mig)) { paused = PAUSE_YIELD; break; }
+          slice_count = 0;        // nobody waits: keep the slot for another slice
+        }
       } else if constexpr (SLICE) {
-        if (slice_its > 0 && ++slice_count >= slice_its) { paused = true; break; }
+        if (slice_its > 0 && ++slice_count >= slice_its) { paused = PAUSE_YIELD; break; }
       }
     }
     if (bad) stop = 2;
@@ -558,7 +585,7 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
     out.stop = stop;
     out.n_accept = n_accept;
     out.Delta = Delta;
-    out.paused = paused ? 1 : 0;
+    out.paused = paused;
 }
 
 }  // namespace gik

@@ -121,6 +121,10 @@ struct SolveArgs {
   // mig_credits / mig_simd_run as in MigCtl; q_tail / q_seq / q_ids / q_state / q_done as for slicing
   unsigned int *q_head;
   int *mig_credits, *mig_simd_run;
+  // round-robin slicing of the wavefront kernel: yield queue (y_seq[k] == k + 1 once entry k is published)
+  unsigned int *y_head, *y_tail, *y_seq;
+  int *y_ids;
+  unsigned int y_cap;
   unsigned int *q_tail, *q_done;   // next to work_counter (= the ticket counter)
   int *q_ids;                      // [cap]
   unsigned int *q_seq;             // [cap], 0xffffffff = not published
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
   }
   const Params &p = a.p;
   int pass = 0;
-  MigCtl mig = {a.mig_credits, a.mig_simd_run, 0};
+  MigCtl mig = {a.mig_credits, a.mig_simd_run, 0, a.work_counter, a.y_head, a.y_tail, a.B, a.y_cap};
   bool tail = false;
   if constexpr (MIG) mig.sid = hw_simd_id();
   for (;;) {
@@ -227,8 +231,22 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
               __hip_atomic_fetch_add(&mig.simd_run[mig.sid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
-          if (b < 0) {
-            b = mig_wait(mig, a.q_head, a.q_seq, a.q_ids, a.q_done, a.B);
+          if (b < 0) {      // no fresh problem left: the oldest yielder, if any ...
+            for (;;) {
+              const unsigned int h = __hip_atomic_load(a.y_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (h >= __hip_atomic_load(a.y_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+              unsigned int expect = h;
+              if (__hip_atomic_compare_exchange_strong(a.y_head, &expect, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT)) {
+                while (__hip_atomic_load(&a.y_seq[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != h + 1u)
+                  __builtin_amdgcn_s_sleep(2);      // (its publisher is between the tail increment and this store)
+                b = __hip_atomic_load(&a.y_ids[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&mig.simd_run[mig.sid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+            if (b < 0)        // ... else wait as a helper of the tail spreading
+              b = mig_wait(mig, a.q_head, a.q_seq, a.q_ids, a.q_done, a.B);
             resumed = 1;
           }
         }
@@ -269,8 +287,8 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
       rs.resumed = resumed;
       const double *src = resumed ? a.Y_out : a.Y_init;
       x = cx.active ? __builtin_nontemporal_load(&src[(size_t)b * NK + lane]) : 0.0;
-      rtr_solve_one<K, THETA_ONE, true, Ctx, true>(cx, p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro, rs, 0,
-                                                   &mig);
+      rtr_solve_one<K, THETA_ONE, true, Ctx, true>(cx, p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro, rs,
+                                                   a.slice_its, &mig);
       if (cx.active) a.Y_out[(size_t)b * NK + lane] = x;
       if (UNI(ro.paused)) {
         if (lane == 0) {
@@ -284,10 +302,16 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
         }
         __threadfence();
         if (lane == 0) {
-          requeue_work(a.q_tail, a.q_ids, a.q_seq, a.B, b);
+          if (ro.paused == PAUSE_DONATE) {
+            requeue_work(a.q_tail, a.q_ids, a.q_seq, a.B, b);      // a helper holds the ticket for it
+          } else {                                                   // yield: behind everything that waits
+            const unsigned int k = atomicAdd(a.y_tail, 1u);
+            __hip_atomic_store(&a.y_ids[k], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.y_seq[k], k + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          }
           __hip_atomic_fetch_add(&mig.simd_run[mig.sid], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        tail = true;
+        if (ro.paused == PAUSE_DONATE) tail = true;
         continue;
       }
     } else {
@@ -888,6 +912,7 @@ struct gik_template {
   int dbg;            // SolveArgs::dbg
   int wpc_override;   // persistent waves per CU, 0 = automatic
   int slice_its;      // time slice of the block kernel in outer iterations, 0 = off
+  int wave_slice_its; // round-robin slice of the wavefront kernel (large batches), 0 = off
   int waves_per_cu;  // resident solve wavefronts per CU (from the occupancy query)
   size_t smem_bytes;
   bool is_block;  // workgroup-per-problem path
@@ -1235,7 +1260,8 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   t->slice_its = d->slice_outer_its < 0 ? 96 : d->slice_outer_its;   // table scene, 4096 goals: 0 / 256 / 96 / 64 -> 795 / 918 / 929 / 926 solves/s
   // developer overrides, read once here (never inside a batch call)
   if (const char *e = getenv("GIK_WAVES_PER_CU")) t->wpc_override = std::max(1, atoi(e));
-  if (const char *e = getenv("GIK_SLICE")) t->slice_its = std::max(0, atoi(e));
+  t->wave_slice_its = d->slice_outer_its < 0 ? 64 : d->slice_outer_its;
+  if (const char *e = getenv("GIK_SLICE")) t->slice_its = t->wave_slice_its = std::max(0, atoi(e));
   t->d_slot_meta = nullptr;
   t->d_counters = nullptr;
   t->next_counter = 0;
@@ -1788,6 +1814,9 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   const bool cg = t->solver == GIK_SOLVER_CONJUGATE_GRADIENT;
   if (!t->is_block || cg || B <= grid || (a.dbg & 1) || slice <= 0 || t->p.maxiter <= slice) slice = 0;
   a.slice_its = slice;
+  a.y_head = a.y_tail = a.y_seq = nullptr;
+  a.y_ids = nullptr;
+  a.y_cap = 0;
   a.q_tail = a.q_done = a.q_head = nullptr;
   a.mig_credits = a.mig_simd_run = nullptr;
   a.q_ids = nullptr;
@@ -1801,9 +1830,13 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   gik_template::SliceWs *sw = nullptr;
   if (slice > 0 || mig) {
     const size_t cap = mig ? (size_t)B + (size_t)grid + 64 : (size_t)B * (size_t)(t->p.maxiter / slice + 1);
-    const size_t off_simd = 16, off_seq = off_simd + (mig ? sizeof(int) * MIG_SIMDS : 0), off_ids = off_seq + cap * 4,
-                 off_state = (off_ids + cap * 4 + 15) & ~(size_t)15;
-    const size_t bytes = off_state + (size_t)B * sizeof(SliceState);
+    // wavefront kernel: round-robin slicing (slice length: the handle's, default 64 outer iterations)
+    const int wslice = (mig && !(a.dbg & 1024)) ? t->wave_slice_its : 0;
+    const size_t ycap = wslice > 0 ? (size_t)16 * B + 8192 : 0;
+    const size_t off_simd = 32, off_seq = off_simd + (mig ? sizeof(int) * MIG_SIMDS : 0), off_ids = off_seq + cap * 4,
+                 off_state = (off_ids + cap * 4 + 15) & ~(size_t)15,
+                 off_yseq = off_state + (((size_t)B * sizeof(SliceState) + 15) & ~(size_t)15), off_yids = off_yseq + ycap * 4;
+    const size_t bytes = off_yids + ycap * 4;
     sw = &mt->slice_ws[mt->next_slice++ % (unsigned)t->slice_pool];
     if (!sw->done && hipEventCreateWithFlags(&sw->done, hipEventDisableTiming) != hipSuccess)
       return fail("hipEventCreate failed");
@@ -1826,9 +1859,16 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     a.q_seq = reinterpret_cast<unsigned int *>(base + off_seq);
     a.q_ids = reinterpret_cast<int *>(base + off_ids);
     a.q_state = reinterpret_cast<SliceState *>(base + off_state);
+    a.y_head = a.q_tail + 4;
+    a.y_tail = a.q_tail + 5;
+    a.y_seq = reinterpret_cast<unsigned int *>(base + off_yseq);
+    a.y_ids = reinterpret_cast<int *>(base + off_yids);
+    a.y_cap = (unsigned int)ycap;
+    if (mig) a.slice_its = wslice;
     HIP_OK(hipMemsetAsync(base, 0, off_seq, (hipStream_t)stream));
     HIP_OK(hipMemsetAsync(a.q_seq, 0xFF, cap * 4, (hipStream_t)stream));
     if (mig) HIP_OK(hipMemsetAsync(a.q_state, 0, (size_t)B * sizeof(SliceState), (hipStream_t)stream));
+    if (ycap) HIP_OK(hipMemsetAsync(a.y_seq, 0, ycap * 4, (hipStream_t)stream));
   }
   if (t->is_block) {
     void (*kern)(SolveArgs, int) =

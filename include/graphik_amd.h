@@ -71,15 +71,16 @@ typedef struct {
    * environment variables GIK_WAVES_PER_CU / GIK_SLICE / GIK_DBG are read ONCE, at
    * gik_template_create, as developer overrides of these fields)                             */
   int32_t waves_per_cu;      /* persistent solve waves (workgroups) per CU; 0 = automatic      */
-  int32_t slice_outer_its;   /* time slice of the workgroup-per-problem kernel in outer
-                                iterations; -1 = default (96), 0 = no time slicing             */
+  int32_t slice_outer_its;   /* time slice in outer iterations: a problem yields its slot to whatever
+                                waits after that many; -1 = default (workgroup kernel 96, wavefront
+                                kernel 64 -- there only for batches beyond the resident waves), 0 = off */
   int32_t debug_flags;       /* developer flags (gik_solve.hip: SolveArgs::dbg); 16 = rerun tCG
                                 after a rejected step instead of resuming from the checkpoint;
                                 workgroup path: 64 = closed form for rigid cliques from 4 nodes
                                 up (default: 16 nodes); 128 / 256 = older spellings of
-                                clique_closed_form = GIK_CLIQUE_OFF / GIK_CLIQUE_DENSE; 512 = no tail
-                                spreading on the wavefront kernel (a scheduling measure of large
-                                batches, bit-neutral: tests compare both settings)                 */
+                                clique_closed_form = GIK_CLIQUE_OFF / GIK_CLIQUE_DENSE; 512 = neither round-robin
+                                slicing nor tail spreading on the wavefront kernel, 1024 = no slicing
+                                (scheduling measures of large batches, bit-neutral: tests compare) */
   /* which of the reference's two solvers gik_solve_batch runs (riemannian_solver.py:40-65):
    * GIK_SOLVER_TRUST_REGIONS (default) or GIK_SOLVER_CONJUGATE_GRADIENT = pymanopt 0.2.5
    * ConjugateGradient + LineSearchAdaptive as configured at :51-59.  The CG defaults of
