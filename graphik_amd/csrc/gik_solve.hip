@@ -144,10 +144,15 @@ __device__ inline int hw_simd_id() {
 // done (-> -1) or a paused problem is handed to this wave (-> its index).  The wave first has to
 // find its SIMD empty and reserve it; while the SIMD is busy with the partner wave's problem it
 // polls slowly.
+// (-2: the yield queue of the round-robin slicing has an entry again -- the caller goes back to it; a
+// helper only commits to a hand-over ticket while that queue is empty.)
 __device__ inline int mig_wait(const MigCtl &m, unsigned int *q_head, const unsigned int *q_seq, const int *q_ids,
                                const unsigned int *q_done, int B) {
   for (;;) {
     if (__hip_atomic_load(q_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)B) return -1;
+    if (__hip_atomic_load(m.y_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+        __hip_atomic_load(m.y_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      return -2;
     int expect = 0;
     if (__hip_atomic_load(&m.simd_run[m.sid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
         __hip_atomic_compare_exchange_strong(&m.simd_run[m.sid], &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
@@ -161,7 +166,7 @@ __device__ inline int mig_wait(const MigCtl &m, unsigned int *q_head, const unsi
         __builtin_amdgcn_s_sleep(64);
       }
     }
-    for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);   // ~25 us
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);   // ~7 us
   }
 }
 
@@ -231,23 +236,24 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
               __hip_atomic_fetch_add(&mig.simd_run[mig.sid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
-          if (b < 0) {      // no fresh problem left: the oldest yielder, if any ...
+          if (b < 0) {      // no fresh problem left: the oldest yielder, if any, else a hand-over
+            resumed = 1;
             for (;;) {
               const unsigned int h = __hip_atomic_load(a.y_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (h >= __hip_atomic_load(a.y_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-              unsigned int expect = h;
-              if (__hip_atomic_compare_exchange_strong(a.y_head, &expect, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT)) {
+              if (h < __hip_atomic_load(a.y_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                unsigned int expect = h;
+                if (!__hip_atomic_compare_exchange_strong(a.y_head, &expect, h + 1u, __ATOMIC_RELAXED,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                  continue;
                 while (__hip_atomic_load(&a.y_seq[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != h + 1u)
                   __builtin_amdgcn_s_sleep(2);      // (its publisher is between the tail increment and this store)
                 b = __hip_atomic_load(&a.y_ids[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(&mig.simd_run[mig.sid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
               }
-            }
-            if (b < 0)        // ... else wait as a helper of the tail spreading
               b = mig_wait(mig, a.q_head, a.q_seq, a.q_ids, a.q_done, a.B);
-            resumed = 1;
+              if (b != -2) break;       // a handed-over problem, or -1: everything is done
+            }
           }
         }
         b = __builtin_amdgcn_readlane(b, 0);  // lane 0 explicitly, independent of exec
