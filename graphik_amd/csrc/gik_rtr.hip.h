@@ -40,6 +40,7 @@ struct RtrResume {
   double Delta;
   int kiter, inner_total, inner_exec, n_accept;
   int resumed;
+  int resumes;    // (bookkeeping of the kernels, not read by the solver)
 };
 
 // ||g||_F together with <g, pk2_m> in one reduction
@@ -87,10 +88,14 @@ struct MigCtl {
   int *simd_run;     // [MIG_SIMDS] problems running or reserved per physical SIMD
   int sid;           // this wave's SIMD (XCC, SE, SH, CU, SIMD bits of the hardware id registers)
   const unsigned int *fresh;    // ticket counter of the fresh problems (tickets < B)
-  const unsigned int *y_head;   // yield queue: entries claimed ...
-  const unsigned int *y_tail;   // ... and published
+  const int *y_avail;           // yield queue: entries nobody has a claim on yet (see SolveArgs)
+  const unsigned int *y_tail;   // ... entries pushed so far
   int B;
   unsigned int y_cap;           // entries of the yield queue (no yield once it is nearly full)
+  const unsigned int *done;     // problems finished so far
+  int waves;                    // persistent waves of the launch: with B - done <= waves every unfinished
+                                // problem can have a slot -- no more yields, helpers may commit to hand-overs
+  int slice_cycles;             // shortest slice in cycles of the shader clock counter
 };
 enum { PAUSE_NONE = 0, PAUSE_DONATE = 1, PAUSE_YIELD = 2 };
 constexpr int MIG_SIMDS = 1 << 14;
@@ -110,15 +115,16 @@ __device__ inline bool mig_poll(const Ctx &cx, const MigCtl &m) {
   return __builtin_amdgcn_readfirstlane(go) != 0;
 }
 
-// is anything waiting for a slot?  (one thread's loads, broadcast)
+// are there more unfinished problems than slots?  (one thread's loads, broadcast.)  Only then does a
+// yield give a waiting problem a turn; with fewer, an entry in the yield queue is just another yielder
+// on its way back to a slot, and yielding to it would go on for ever.
 template <typename Ctx>
 __device__ inline bool mig_anyone_waiting(const Ctx &cx, const MigCtl &m) {
   int w = 0;
   if (cx.lead()) {
     const unsigned int yt = __hip_atomic_load(m.y_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    w = yt + 4096u < m.y_cap &&
-        (__hip_atomic_load(m.fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)m.B ||
-         __hip_atomic_load(m.y_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < yt);
+    const unsigned int dn = __hip_atomic_load(m.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w = yt + 4096u < m.y_cap && (unsigned)m.B > dn + (unsigned)m.waves;
   }
   return __builtin_amdgcn_readfirstlane(w) != 0;
 }
@@ -148,6 +154,7 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
     int kiter = SLICE ? rs.kiter : 0, inner_total = SLICE ? rs.inner_total : 0,
         inner_exec = SLICE ? rs.inner_exec : 0, n_accept = SLICE ? rs.n_accept : 0, stop = 1;
     int slice_count = 0;
+    long long slice_t0 = MIG ? (long long)__builtin_readcyclecounter() : 0;
     int paused = PAUSE_NONE;
     // ---- Retrace (k = 3 wave path) --------------------------------------------------------
     // A rejected step leaves x, g and the Hessian unchanged and divides the radius by 4
@@ -560,9 +567,14 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
       if constexpr (MIG) {
         ++slice_count;
         if ((kiter & 3) == 0 && mig_poll(cx, *mig)) { paused = PAUSE_DONATE; break; }
-        if (slice_its > 0 && slice_count >= slice_its) {
+        // a slice is at least `slice_its` outer iterations AND mig->slice_cycles long (a hand-over
+        // costs the ~10 us of saving / reloading the point and re-evaluating cost and gradient:
+        // the lower bound in time keeps that negligible for problems with very cheap iterations)
+        if (slice_its > 0 && slice_count >= slice_its &&
+            (long long)__builtin_readcyclecounter() - slice_t0 > (long long)mig->slice_cycles) {
           if (mig_anyone_waiting(cx, *mig)) { paused = PAUSE_YIELD; break; }
           slice_count = 0;        // nobody waits: keep the slot for another slice
+          slice_t0 = (long long)__builtin_readcyclecounter();
         }
       } else if constexpr (SLICE) {
         if (slice_its > 0 && ++slice_count >= slice_its) { paused = PAUSE_YIELD; break; }

@@ -30,6 +30,7 @@ namespace gik {
 struct SliceState {
   double Delta;
   int kiter, inner_total, inner_exec, n_accept;
+  int resumes, pad;    // times the problem changed hands (reported in gik_stats.flags >> 8)
 };
 
 // Claim the next piece of work for this wave / workgroup (called by one thread).  Returns the
@@ -67,6 +68,7 @@ __device__ inline RtrResume load_slice_state(const SliceState *st) {
   rs.inner_total = uniform_i32(__builtin_nontemporal_load(&st->inner_total));
   rs.inner_exec = uniform_i32(__builtin_nontemporal_load(&st->inner_exec));
   rs.n_accept = uniform_i32(__builtin_nontemporal_load(&st->n_accept));
+  rs.resumes = uniform_i32(__builtin_nontemporal_load(&st->resumes));
   rs.resumed = 1;
   return rs;
 }
@@ -117,13 +119,20 @@ struct SolveArgs {
   // ticket B + t is the t-th re-queued problem, published in q_ids[t] / q_seq[t] (no slot is ever
   // reused: the ring has room for every possible re-queue of the launch).
   int slice_its;
+  int slice_cycles;   // wavefront kernel: shortest round-robin slice (MigCtl::slice_cycles)
   // tail spreading (wavefront kernel, MIG variant): q_head = hand-over tickets taken by helpers,
   // mig_credits / mig_simd_run as in MigCtl; q_tail / q_seq / q_ids / q_state / q_done as for slicing
   unsigned int *q_head;
   int *mig_credits, *mig_simd_run;
   // round-robin slicing of the wavefront kernel: yield queue (y_seq[k] == k + 1 once entry k is published)
+  // Entries are taken by fetch-add tickets on y_head, never by compare-and-swap (2048 waves that
+  // retry a CAS on one word serve ~50 k claims per second -- measured, the whole batch then waits for
+  // its queue).  That needs a guarantee that a ticket's entry exists: a wave that yields pushes
+  // first, so it owns one entry's worth of claim (it either pops at once, or, if it got a fresh
+  // problem instead, passes the claim on by y_avail += 1); a wave that comes from a finished
+  // problem has to win one from y_avail (fetch-add -1, undone if it went negative).
   unsigned int *y_head, *y_tail, *y_seq;
-  int *y_ids;
+  int *y_ids, *y_avail;
   unsigned int y_cap;
   unsigned int *q_tail, *q_done;   // next to work_counter (= the ticket counter)
   int *q_ids;                      // [cap]
@@ -150,11 +159,12 @@ __device__ inline int mig_wait(const MigCtl &m, unsigned int *q_head, const unsi
                                const unsigned int *q_done, int B) {
   for (;;) {
     if (__hip_atomic_load(q_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)B) return -1;
-    if (__hip_atomic_load(m.y_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-        __hip_atomic_load(m.y_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      return -2;
+    if (__hip_atomic_load(m.y_avail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) return -2;
     int expect = 0;
-    if (__hip_atomic_load(&m.simd_run[m.sid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+    // (commit to a hand-over only in the tail: while there are more unfinished problems than waves the
+    // yield queue refills at once)
+    if ((unsigned)B <= __hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (unsigned)m.waves &&
+        __hip_atomic_load(&m.simd_run[m.sid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
         __hip_atomic_compare_exchange_strong(&m.simd_run[m.sid], &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT)) {
       const unsigned int t = __hip_atomic_fetch_add(q_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -169,6 +179,19 @@ __device__ inline int mig_wait(const MigCtl &m, unsigned int *q_head, const unsi
     for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);   // ~7 us
   }
 }
+
+#ifdef GIK_DEV
+// event log of the scheduling probes: dbg_buf[8] = entries, entry e at 16 + 4 e = {time in 10 ns, wave, type, problem}
+__device__ inline void dev_log(double *buf, int type, int b) {
+  const int e = (int)atomicAdd(&buf[8], 1.0);
+  if (e >= 250000) return;
+  double *p = buf + 16 + 4 * (size_t)e;
+  p[0] = (double)__builtin_amdgcn_s_memrealtime();
+  p[1] = (double)blockIdx.x;
+  p[2] = (double)type;
+  p[3] = (double)b;
+}
+#endif
 
 // Stage the launch-invariant slot table into LDS and zero the gather tiles (idle lanes and
 // padding slots read the never-written dump row, which must hold finite zeros).
@@ -213,11 +236,20 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
   }
   const Params &p = a.p;
   int pass = 0;
-  MigCtl mig = {a.mig_credits, a.mig_simd_run, 0, a.work_counter, a.y_head, a.y_tail, a.B, a.y_cap};
+  MigCtl mig = {a.mig_credits, a.mig_simd_run, 0, a.work_counter, a.y_avail, a.y_tail, a.B, a.y_cap, a.q_done,
+                (int)gridDim.x, a.slice_cycles};
   bool tail = false;
+  bool owns_entry = false;    // (lane 0) this wave has just pushed a yielded problem
   if constexpr (MIG) mig.sid = hw_simd_id();
+#ifdef GIK_DEV
+  long long dev_t_start = (long long)__builtin_readcyclecounter(), dev_t_solve = 0, dev_t_claim = 0;
+  int dev_n_claim = 0;
+#endif
   for (;;) {
     int b = 0, resumed = 0;
+#ifdef GIK_DEV
+    const long long dev_tc = (long long)__builtin_readcyclecounter();
+#endif
     if constexpr (MIG) {
       // (the static block -> problem alternative is never selected together with MIG on the host; it
       // is what keeps the compiler's divergence analysis from treating this loop's exit as divergent
@@ -236,30 +268,41 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
               __hip_atomic_fetch_add(&mig.simd_run[mig.sid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
+          if (b >= 0 && owns_entry)      // this wave's yield stays in the queue: somebody else's to take
+            __hip_atomic_fetch_add(a.y_avail, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
           if (b < 0) {      // no fresh problem left: the oldest yielder, if any, else a hand-over
             resumed = 1;
-            for (;;) {
-              const unsigned int h = __hip_atomic_load(a.y_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (h < __hip_atomic_load(a.y_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                unsigned int expect = h;
-                if (!__hip_atomic_compare_exchange_strong(a.y_head, &expect, h + 1u, __ATOMIC_RELAXED,
-                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                  continue;
-                while (__hip_atomic_load(&a.y_seq[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != h + 1u)
-                  __builtin_amdgcn_s_sleep(2);      // (its publisher is between the tail increment and this store)
-                b = __hip_atomic_load(&a.y_ids[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(&mig.simd_run[mig.sid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
+            bool pop = owns_entry;
+            while (!pop) {
+              if (__hip_atomic_load(a.y_avail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
+                if (__hip_atomic_fetch_add(a.y_avail, -1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) > 0) {
+                  pop = true;
+                  break;
+                }
+                __hip_atomic_fetch_add(a.y_avail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               }
               b = mig_wait(mig, a.q_head, a.q_seq, a.q_ids, a.q_done, a.B);
               if (b != -2) break;       // a handed-over problem, or -1: everything is done
             }
+            if (pop) {
+              const unsigned int h = __hip_atomic_fetch_add(a.y_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              while (__hip_atomic_load(&a.y_seq[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != h + 1u)
+                __builtin_amdgcn_s_sleep(2);      // (its publisher is between the tail increment and this store)
+              b = __hip_atomic_load(&a.y_ids[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_fetch_add(&mig.simd_run[mig.sid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
+          owns_entry = false;
         }
         b = __builtin_amdgcn_readlane(b, 0);  // lane 0 explicitly, independent of exec
         resumed = __builtin_amdgcn_readlane(resumed, 0);
       }
       tail = tail || resumed;
+#ifdef GIK_DEV
+      dev_t_claim += (long long)__builtin_readcyclecounter() - dev_tc;
+      ++dev_n_claim;
+      if ((a.dbg & 4096) && a.dbg_buf && lane == 0) dev_log(a.dbg_buf, resumed ? 1 : 0, b);
+#endif
       if (UNI(b < 0)) break;
     } else {
       if (a.dbg & 1) {
@@ -284,6 +327,7 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
     }
     RtrOut ro;
     double x;
+    int rs_resumes = 0;
     if constexpr (MIG) {
       // Branch-free on purpose: q_state is zeroed at launch, so a fresh problem reads zeros (a
       // conditional load here made the compiler treat the solver's counters as divergent and wrap
@@ -291,10 +335,17 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
       // another CU: cache-bypassing loads.)
       RtrResume rs = load_slice_state(&a.q_state[b]);
       rs.resumed = resumed;
+      rs_resumes = rs.resumes;
       const double *src = resumed ? a.Y_out : a.Y_init;
       x = cx.active ? __builtin_nontemporal_load(&src[(size_t)b * NK + lane]) : 0.0;
+#ifdef GIK_DEV
+      const long long dev_ts = (long long)__builtin_readcyclecounter();
+#endif
       rtr_solve_one<K, THETA_ONE, true, Ctx, true>(cx, p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro, rs,
                                                    a.slice_its, &mig);
+#ifdef GIK_DEV
+      dev_t_solve += (long long)__builtin_readcyclecounter() - dev_ts;
+#endif
       if (cx.active) a.Y_out[(size_t)b * NK + lane] = x;
       if (UNI(ro.paused)) {
         if (lane == 0) {
@@ -304,9 +355,14 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
           st.inner_total = ro.inner_total;
           st.inner_exec = ro.inner_executed;
           st.n_accept = ro.n_accept;
+          st.resumes = rs.resumes + 1;
+          st.pad = 0;
           a.q_state[b] = st;
         }
         __threadfence();
+#ifdef GIK_DEV
+        if ((a.dbg & 4096) && a.dbg_buf && lane == 0) dev_log(a.dbg_buf, ro.paused == PAUSE_DONATE ? 3 : 2, b);
+#endif
         if (lane == 0) {
           if (ro.paused == PAUSE_DONATE) {
             requeue_work(a.q_tail, a.q_ids, a.q_seq, a.B, b);      // a helper holds the ticket for it
@@ -314,6 +370,7 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
             const unsigned int k = atomicAdd(a.y_tail, 1u);
             __hip_atomic_store(&a.y_ids[k], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.y_seq[k], k + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            owns_entry = true;
           }
           __hip_atomic_fetch_add(&mig.simd_run[mig.sid], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -322,7 +379,7 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
       }
     } else {
       x = cx.active ? a.Y_init[(size_t)b * NK + lane] : 0.0;
-      const RtrResume rs = {0.0, 0, 0, 0, 0, 0};
+      const RtrResume rs = {0.0, 0, 0, 0, 0, 0, 0};
       rtr_solve_one<K, THETA_ONE, false>(cx, p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro, rs, 0);
       if (cx.active) a.Y_out[(size_t)b * NK + lane] = x;
     }
@@ -335,15 +392,26 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
       s.stop = ro.stop;
       s.n_accept = ro.n_accept;
       s.inner_executed = ro.inner_executed;
-      s.flags = (MIG && resumed) ? 2 : 0;
+      s.flags = (MIG && resumed) ? (2 | (rs_resumes << 8)) : 0;
       s.stepsize = ro.Delta;
       a.stats[b] = s;
+#ifdef GIK_DEV
+      if (MIG && (a.dbg & 4096) && a.dbg_buf) dev_log(a.dbg_buf, 4, b);
+#endif
       if constexpr (MIG) {
         __hip_atomic_fetch_add(&mig.simd_run[mig.sid], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(a.q_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
+#ifdef GIK_DEV
+  if (MIG && (a.dbg & 4096) && a.dbg_buf && lane == 0) {
+    atomicAdd(&a.dbg_buf[4], (double)dev_t_solve);
+    atomicAdd(&a.dbg_buf[5], (double)dev_t_claim);
+    atomicAdd(&a.dbg_buf[6], (double)((long long)__builtin_readcyclecounter() - dev_t_start));
+    atomicAdd(&a.dbg_buf[7], (double)dev_n_claim);
+  }
+#endif
 }
 
 // Riemannian conjugate gradients (the reference's alternative solver), same persistent scheme
@@ -510,7 +578,7 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
     __syncthreads();
     if (UNI(b < 0)) break;
     cx.load_problem(a.targets + (size_t)b * a.T, a.bt, sh_tgt);
-    RtrResume rs = {0.0, 0, 0, 0, 0, 0};
+    RtrResume rs = {0.0, 0, 0, 0, 0, 0, 0};
     double x = 0.0;
     if (resumed) {
       rs = load_slice_state(&a.q_state[b]);
@@ -532,6 +600,8 @@ __global__ void __launch_bounds__(BLOCK_NT) rtr_block_kernel(SolveArgs a, int SL
         st.inner_total = ro.inner_total;
         st.inner_exec = ro.inner_executed;
         st.n_accept = ro.n_accept;
+        st.resumes = rs.resumes + 1;
+        st.pad = 0;
         a.q_state[b] = st;
       }
       __threadfence();
@@ -919,6 +989,7 @@ struct gik_template {
   int wpc_override;   // persistent waves per CU, 0 = automatic
   int slice_its;      // time slice of the block kernel in outer iterations, 0 = off
   int wave_slice_its; // round-robin slice of the wavefront kernel (large batches), 0 = off
+  int wave_slice_cycles = 2000000;   // ... and its shortest duration (GIK_SLICE_CYCLES)
   int waves_per_cu;  // resident solve wavefronts per CU (from the occupancy query)
   size_t smem_bytes;
   bool is_block;  // workgroup-per-problem path
@@ -1268,6 +1339,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   if (const char *e = getenv("GIK_WAVES_PER_CU")) t->wpc_override = std::max(1, atoi(e));
   t->wave_slice_its = d->slice_outer_its < 0 ? 64 : d->slice_outer_its;
   if (const char *e = getenv("GIK_SLICE")) t->slice_its = t->wave_slice_its = std::max(0, atoi(e));
+  if (const char *e = getenv("GIK_SLICE_CYCLES")) t->wave_slice_cycles = std::max(0, atoi(e));
   t->d_slot_meta = nullptr;
   t->d_counters = nullptr;
   t->next_counter = 0;
@@ -1780,10 +1852,10 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   a.dbg = t->dbg;
   a.dbg_buf = nullptr;
 #ifdef GIK_DEV
-  if (a.dbg & (4 | 8)) {
+  if (a.dbg & (4 | 8 | 4096)) {
     static double *buf = nullptr;
-    if (!buf) (void)hipMalloc((void **)&buf, 64 * 128 * 4 * sizeof(double));
-    (void)hipMemset(buf, 0, 64 * 128 * 4 * sizeof(double));
+    if (!buf) (void)hipMalloc((void **)&buf, (1 << 20) * sizeof(double));
+    (void)hipMemset(buf, 0, (1 << 20) * sizeof(double));
     a.dbg_buf = buf;
     g_dbg_buf = buf;
   }
@@ -1821,7 +1893,7 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   if (!t->is_block || cg || B <= grid || (a.dbg & 1) || slice <= 0 || t->p.maxiter <= slice) slice = 0;
   a.slice_its = slice;
   a.y_head = a.y_tail = a.y_seq = nullptr;
-  a.y_ids = nullptr;
+  a.y_ids = a.y_avail = nullptr;
   a.y_cap = 0;
   a.q_tail = a.q_done = a.q_head = nullptr;
   a.mig_credits = a.mig_simd_run = nullptr;
@@ -1867,10 +1939,11 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     a.q_state = reinterpret_cast<SliceState *>(base + off_state);
     a.y_head = a.q_tail + 4;
     a.y_tail = a.q_tail + 5;
+    a.y_avail = reinterpret_cast<int *>(a.q_tail + 6);
     a.y_seq = reinterpret_cast<unsigned int *>(base + off_yseq);
     a.y_ids = reinterpret_cast<int *>(base + off_yids);
     a.y_cap = (unsigned int)ycap;
-    if (mig) a.slice_its = wslice;
+    if (mig) { a.slice_its = wslice; a.slice_cycles = t->wave_slice_cycles; }
     HIP_OK(hipMemsetAsync(base, 0, off_seq, (hipStream_t)stream));
     HIP_OK(hipMemsetAsync(a.q_seq, 0xFF, cap * 4, (hipStream_t)stream));
     if (mig) HIP_OK(hipMemsetAsync(a.q_state, 0, (size_t)B * sizeof(SliceState), (hipStream_t)stream));

@@ -149,12 +149,15 @@ def test_full_size_c5_planar(torch_cuda, name, B):
     assert np.mean((r["f"][:n] < 1e-9) == (o["f(x)"] < 1e-9)) > 0.97
 
 
-def test_tail_spreading_is_bit_identical(torch_cuda):
-    """Wavefront kernel, batches beyond the resident waves (two waves per SIMD): once the queue is
-    empty a wave whose SIMD hosts two long-running problems hands its problem -- (x, Delta,
-    counters), exactly resumable -- to a wave that waits on an empty SIMD.  Every output must equal
-    the run with debug_flags = 512 (no hand-overs) bit for bit, hand-overs must actually happen, and
-    a batch in which every problem is long (maxiter-bound start points) must terminate."""
+def test_tail_spreading_and_round_robin_are_bit_identical(torch_cuda, monkeypatch):
+    """Wavefront kernel, batches beyond the resident waves (two waves per SIMD).  Two schedulers
+    ride on the exactly resumable state (x, Delta, counters): round-robin time slicing while more
+    problems are unfinished than there are waves (a problem gives up its slot after a slice and
+    queues behind the others), and in the tail a wave whose SIMD hosts two long-running problems
+    hands its problem to a wave that waits on an empty SIMD.  Every output must equal the run with
+    debug_flags = 512 (neither) bit for bit -- also with slices of 4 outer iterations, i.e. ~10^5
+    hand-overs --, hand-overs must actually happen, and a batch in which every problem is long
+    (maxiter-bound start points) must terminate."""
     from graphik_amd.solvers.riemannian_solver import BatchProblem
     robot, graph = make_graph("kuka")
     rs = np.random.RandomState(0)
@@ -162,19 +165,25 @@ def test_tail_spreading_is_bit_identical(torch_cuda):
     Tg = robot.fk_batch(lb + (ub - lb) * rs.rand(65536, robot.n)[:8192])
     keys = ("x", "f", "gradnorm", "iterations", "inner_total", "stop", "n_accept", "stepsize")
     out = {}
-    for name, params in (("spread", None), ("plain", {"debug_flags": 512})):
+    monkeypatch.setenv("GIK_SLICE_CYCLES", "0")      # (read at creation: no lower bound on a slice's duration)
+    for name, params in (("default", None), ("tiny", {"slice_outer_its": 4}), ("spread", {"debug_flags": 1024}),
+                         ("plain", {"debug_flags": 512})):
         prob = BatchProblem(graph, use_limits=True, params=params)
         tg, Y0 = prob.template.prepare(Tg)
         r = prob.template.solve(Y0, tg)
         torch_cuda.cuda.synchronize()
         out[name] = {k: r[k].cpu().numpy() for k in keys + ("flags", "inner_executed")}
-    for k in keys:
-        assert np.array_equal(out["spread"][k], out["plain"][k], equal_nan=True), k
-    moved = (out["spread"]["flags"] & 2) != 0
-    # (a hand-over drops the tCG checkpoint: a moved problem may execute a few products more)
-    assert np.array_equal(out["spread"]["inner_executed"][~moved], out["plain"]["inner_executed"][~moved])
-    assert np.all(out["spread"]["inner_executed"][moved] >= out["plain"]["inner_executed"][moved])
-    assert moved.sum() >= 20 and not (out["plain"]["flags"] & 2).any(), moved.sum()
+    assert not (out["plain"]["flags"] & 2).any()
+    for name, least in (("default", 4000), ("tiny", 100000), ("spread", 20)):
+        for k in keys:
+            assert np.array_equal(out[name][k], out["plain"][k], equal_nan=True), (name, k)
+        moved = (out[name]["flags"] & 2) != 0
+        # (a hand-over drops the tCG checkpoint: a moved problem may execute a few products more)
+        assert np.array_equal(out[name]["inner_executed"][~moved], out["plain"]["inner_executed"][~moved])
+        assert np.all(out[name]["inner_executed"][moved] >= out["plain"]["inner_executed"][moved])
+        handovers = int((out[name]["flags"] >> 8).sum())
+        assert handovers >= least and moved.sum() >= 20, (name, handovers, moved.sum())
+    monkeypatch.delenv("GIK_SLICE_CYCLES")
     # 4096 copies of three slow goals: nothing finishes early, every wave stays busy to the end
     slow = np.argsort(-out["plain"]["iterations"])[:3]
     prob = BatchProblem(graph, use_limits=True, params={"maxiter": 300})
