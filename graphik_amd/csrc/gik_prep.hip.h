@@ -111,12 +111,21 @@ __device__ inline void rr_pair(int n_even, int r, int m, int &p, int &q) {
 // (rotations below that are skipped, so the confirming sweep is cheap; typically 6-7 sweeps).
 // Only the leading n x n block is decomposed (row stride stays N): the scatter matrix of
 // linear_projection is non-zero in its leading K x K block only (K ~ 6 of N = 18).
-__device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, double *cs, int *pq,
+// tab: (ne - 1) * np ints of LDS scratch (ne = n rounded up to even, np = ne / 2): the round-robin
+// pairs of every round, worked out once per call instead of two integer modulos per lane and round.
+__device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, double *cs, int *pq, int *tab,
                                   int lane, int n = -1) {
   if (n < 0) n = N;
   const int stride = N;
   N = n;
   const int ne = N + (N & 1), np = ne / 2;
+  for (int e = lane; e < (ne - 1) * np; e += WAVE) {
+    const int r = e / np;
+    int p, q;
+    rr_pair(ne, r, e - r * np, p, q);
+    tab[e] = p | (q << 8);
+  }
+  __builtin_amdgcn_wave_barrier();
   double fro = 0.0;
   if (lane < N)
     for (int j = 0; j < N; ++j) fro = fma(A[lane * stride + j], A[lane * stride + j], fro);
@@ -126,8 +135,7 @@ __device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, doubl
     for (int r = 0; r < ne - 1; ++r) {
       bool sig = false;
       if (lane < np) {
-        int p, q;
-        rr_pair(ne, r, lane, p, q);
+        const int pair = tab[r * np + lane], p = pair & 0xff, q = pair >> 8;
         double c = 1.0, s = 0.0;
         int code = -1;
         if (q < N) {
@@ -142,7 +150,7 @@ __device__ inline void jacobi_lds(double *A, double *V, int N, int sweeps, doubl
             const double t = (th >= 0.0 ? 1.0 : -1.0) * frcp(fabs(th) + h2 * frsqrt(h2));
             c = frsqrt(fma(t, t, 1.0));
             s = t * c;
-            code = p | (q << 8);
+            code = pair;
           }
         }
         cs[2 * lane] = c;
@@ -282,6 +290,7 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
   double *sg = ev + 32;        // [32] signs*scale
   int *pq = reinterpret_cast<int *>(sg + 32);  // [16]
   int *rk = pq + 16;                           // [32]
+  int *jtab = rk + 32;                         // [(ne - 1) ne / 2], ne = N rounded up to even
   const int D = K + 1;
 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -309,6 +318,9 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
       const double g = src >= 0 ? gd[src] : 0.0;
       a.targets[(size_t)b * pc.T + t] = src >= 0 ? g * g : pc.term_static[t];
     }
+#ifdef GIK_DEV
+    if (a.stop_phase == 1) continue;
+#endif
     // ---- bound smoothing: ub = APSP(UPPER) (Floyd-Warshall), then
     //      lb[u][v] = max(0, max_{a,b} LOWER[a][b] - ub[u][a] - ub[b][v])   (see dgp.py)
     for (int m = 0; m < N; ++m) {
@@ -319,6 +331,9 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
     }
+#ifdef GIK_DEV
+    if (a.stop_phase == 2) continue;
+#endif
     for (int e = lane; e < NN; e += WAVE) {  // A[u][b] = max_a (L[a][b] - U[u][a])
       const int u = e / N, bb = e - u * N;
       double best = -INFINITY;
@@ -333,6 +348,9 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
       V[e] = best;
     }
     __builtin_amdgcn_wave_barrier();
+#ifdef GIK_DEV
+    if (a.stop_phase == 3) continue;
+#endif
     if (a.dbg_lb)
       for (int e = lane; e < NN; e += WAVE) {
         a.dbg_lb[(size_t)b * NN + e] = V[e];
@@ -359,7 +377,13 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
       V[e] = (i == j) ? 1.0 : 0.0;
     }
     __builtin_amdgcn_wave_barrier();
-    jacobi_lds(A, V, N, a.sweeps, cs, pq, lane);
+#ifdef GIK_DEV
+    if (a.stop_phase == 4) continue;
+#endif
+    jacobi_lds(A, V, N, a.sweeps, cs, pq, jtab, lane);
+#ifdef GIK_DEV
+    if (a.stop_phase == 5) continue;
+#endif
     // ---- factor(): clip, scale by sqrt(lambda), order descending (fliplr of ascending)
     if (lane < N) ev[lane] = A[lane * N + lane];
     if (a.dbg_eig && lane < N) a.dbg_eig[((size_t)b * 3 + 0) * N + lane] = A[lane * N + lane];
@@ -392,7 +416,7 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
     if (a.dbg_eig) {   // diagnostics only: the spectrum itself, then A is rebuilt for the count
-      jacobi_lds(A, nullptr, N, a.sweeps, cs, pq, lane);
+      jacobi_lds(A, nullptr, N, a.sweeps, cs, pq, jtab, lane);
       if (lane < N) a.dbg_eig[((size_t)b * 3 + 1) * N + lane] = A[lane * N + lane];
       __builtin_amdgcn_wave_barrier();
       for (int e = lane; e < NN; e += WAVE) {
@@ -401,9 +425,15 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
     }
+#ifdef GIK_DEV
+    if (a.stop_phase == 6) continue;
+#endif
     const int Kc = count_eigs_above_lds(A, N, 1e-8, cs, ev, lane);
     if (a.K_out && lane == 0) a.K_out[b] = Kc;
     __builtin_amdgcn_wave_barrier();
+#ifdef GIK_DEV
+    if (a.stop_phase == 7) continue;
+#endif
     // ---- linear_projection (dgp.py:174-183): scatter of the edge differences of the first Kc
     //      columns, its top-`dim` eigenvectors
     for (int e = lane; e < NN; e += WAVE) {
@@ -424,7 +454,13 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
       V[e] = (r == c) ? 1.0 : 0.0;
     }
     __builtin_amdgcn_wave_barrier();
-    jacobi_lds(A, V, N, a.sweeps, cs, pq, lane, Kc > 1 ? Kc : 2);
+#ifdef GIK_DEV
+    if (a.stop_phase == 8) continue;
+#endif
+    jacobi_lds(A, V, N, a.sweeps, cs, pq, jtab, lane, Kc > 1 ? Kc : 2);
+#ifdef GIK_DEV
+    if (a.stop_phase == 9) continue;
+#endif
     if (lane < N) ev[lane] = (lane < Kc) ? A[lane * N + lane] : -INFINITY;
     if (a.dbg_eig && lane < N) a.dbg_eig[((size_t)b * 3 + 2) * N + lane] = (lane < Kc) ? A[lane * N + lane] : 0.0;
     __builtin_amdgcn_wave_barrier();

@@ -1337,7 +1337,9 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   t->slice_its = d->slice_outer_its < 0 ? 96 : d->slice_outer_its;   // table scene, 4096 goals: 0 / 256 / 96 / 64 -> 795 / 918 / 929 / 926 solves/s
   // developer overrides, read once here (never inside a batch call)
   if (const char *e = getenv("GIK_WAVES_PER_CU")) t->wpc_override = std::max(1, atoi(e));
-  t->wave_slice_its = d->slice_outer_its < 0 ? 64 : d->slice_outer_its;
+  // wavefront kernel: 256 ... 32 iterations per slice give the same time (NOTEBOOK 8.3); the longest of
+  // them moves the fewest problems through HBM (KUKA 65536: 118 k hand-overs of ~1.5 KB instead of 562 k at 64)
+  t->wave_slice_its = d->slice_outer_its < 0 ? 256 : d->slice_outer_its;
   if (const char *e = getenv("GIK_SLICE")) t->slice_its = t->wave_slice_its = std::max(0, atoi(e));
   if (const char *e = getenv("GIK_SLICE_CYCLES")) t->wave_slice_cycles = std::max(0, atoi(e));
   t->d_slot_meta = nullptr;
@@ -1558,7 +1560,8 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   pc.last_along_z = d->last_link_along_z;
   t->pc = pc;
   t->sweeps = d->jacobi_sweeps > 0 ? d->jacobi_sweeps : 10;
-  t->prep_smem = sizeof(double) * ((size_t)5 * N * N + 2 * n_ee * d->n_anchor + pc.n_gg + 96) + sizeof(int) * 48;
+  t->prep_smem = sizeof(double) * ((size_t)5 * N * N + 2 * n_ee * d->n_anchor + pc.n_gg + 96) +
+                 sizeof(int) * (48 + (size_t)((N + 1) / 2) * ((N | 1) + (N + 1) / 2 + 1));   // (+ jacobi_lds's pair tables)
   // graphs beyond one wavefront's LDS: workgroup-per-goal kernel with its matrices in a global slab
   t->prep_block = N > 32 || d->n_anchor > 32 || d->force_block_prepare != 0 ||
                   getenv("GIK_PREP_FORCE_BLOCK") != nullptr;
