@@ -1334,7 +1334,10 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   t->cg.planar_proj_exact = d->planar_proj_exact;
   t->dbg = dbg_eff;
   t->wpc_override = std::max(0, d->waves_per_cu);
-  t->slice_its = d->slice_outer_its < 0 ? 96 : d->slice_outer_its;   // table scene, 4096 goals: 0 / 256 / 96 / 64 -> 795 / 918 / 929 / 926 solves/s
+  // workgroup kernel, table scene, 4096 goals (round 3): slice 96 / 160 / 256 -> 1430 / 1430 / 1409 solves/s and
+  // 755 / 586 / 368 MB of HBM traffic per launch (every resumed slice re-reads the problem's 45 KB of
+  // targets; 207 MB are the algorithmic bytes).  Without slicing: ~15 % slower (round 2: 795 vs 929).
+  t->slice_its = d->slice_outer_its < 0 ? 256 : d->slice_outer_its;
   // developer overrides, read once here (never inside a batch call)
   if (const char *e = getenv("GIK_WAVES_PER_CU")) t->wpc_override = std::max(1, atoi(e));
   // wavefront kernel: 256 ... 32 iterations per slice give the same time (NOTEBOOK 8.3); the longest of
