@@ -174,7 +174,7 @@ def test_tail_spreading_and_round_robin_are_bit_identical(torch_cuda, monkeypatc
         torch_cuda.cuda.synchronize()
         out[name] = {k: r[k].cpu().numpy() for k in keys + ("flags", "inner_executed")}
     assert not (out["plain"]["flags"] & 2).any()
-    for name, least in (("default", 4000), ("tiny", 100000), ("spread", 20)):
+    for name, least in (("default", 2000), ("tiny", 100000), ("spread", 20)):   # measured 6.5 k / 135 k / 450
         for k in keys:
             assert np.array_equal(out[name][k], out["plain"][k], equal_nan=True), (name, k)
         moved = (out[name]["flags"] & 2) != 0
