@@ -78,11 +78,11 @@ __device__ inline double boundary_tau(double e_Pd2, double d_Pd, double Delta2, 
 // resumable from (x, Delta, counters) -- publishes it under the next ticket and turns helper itself.
 // A SIMD's count only ever rises from 0 to 1 in this phase, so a problem moves at most once, and
 // every published problem has a helper waiting for exactly that ticket.  Results are bit-identical
-// to an unmigrated run (tests/test_full_size_gpu.py::test_tail_spreading_is_bit_identical).
-// Round-robin time slicing rides on the same hooks: after `slice_its` outer iterations a problem
-// yields its slot if anything is waiting (an unclaimed fresh problem or an earlier yielder), so that
-// the long problems -- unknown in advance -- are not the last to START; the yielder queues behind
-// everything that waits (MigCtl::wait_*: fresh ticket counter / yield queue head and tail).
+// to an unmigrated run (tests/test_full_size_gpu.py::test_tail_spreading_and_round_robin_are_bit_identical).
+// Round-robin time slicing rides on the same hooks: while more problems are unfinished than the launch
+// has waves, a problem yields its slot after `slice_its` outer iterations, so that the long problems
+// -- unknown in advance -- are not the last to START; the yielder queues behind everything that
+// waits (fresh problems first, then the yield queue in FIFO order; SolveArgs::y_*).
 struct MigCtl {
   int *credits;      // helpers waiting on an empty SIMD, not yet matched with a donor
   int *simd_run;     // [MIG_SIMDS] problems running or reserved per physical SIMD
