@@ -138,8 +138,10 @@ typedef struct {
   int32_t flags;       /* bit 0: workgroup kernels, rigid clique: the clique's target distances were
                           those of a point set in R^3 and its dense D w product was replaced by
                           moments (informational; results agree to round-off either way);
-                          bit 1: wavefront kernel, tail of a large batch: the problem was paused and
-                          finished by a wave on another, idle SIMD (same result bit for bit)      */
+                          bit 1: wavefront kernel, large batch: the problem was paused at least once
+                          (round-robin time slice, or handed to a wave on an idle SIMD in the tail)
+                          and resumed by another wave (same result bit for bit); bits 8..31: how
+                          often.  Bit 1, bits 8.. and inner_executed depend on timing            */
   double stepsize;     /* ConjugateGradient: step of the last line search (the `stepsize` entry of
                           pymanopt's final_values); TrustRegions: trust-region radius at return  */
 } gik_stats;            /* 48 bytes                                                         */
