@@ -1909,12 +1909,15 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   // Tail spreading (wavefront kernel): only where two waves share a SIMD and the batch outlasts
   // the queue -- more problems than resident waves -- and only on the tuned default variant
   // (trust-region solver, theta = 1, not anchored).  debug_flags 512 turns it off (tests compare).
+  // (At one wave per SIMD -- batches up to 6 problems per SIMD -- round-robin slicing LOSES 5-8 %: a
+  // straggler that happens to start at t = 0 is better off keeping its slot than sharing it for the
+  // first ~20 ms; measured on 4096 LWA4D / KUKA / UR10 goals, four seeds each, tools/attic/dev_rr_midbatch.py.)
   const bool mig = !t->is_block && !cg && !t->anchored && t->variant->solve_mig && t->p.theta == 1.0 &&
                    wpc > 4 && B > grid && !(a.dbg & (1 | 512));
   gik_template::SliceWs *sw = nullptr;
   if (slice > 0 || mig) {
     const size_t cap = mig ? (size_t)B + (size_t)grid + 64 : (size_t)B * (size_t)(t->p.maxiter / slice + 1);
-    // wavefront kernel: round-robin slicing (slice length: the handle's, default 64 outer iterations)
+    // wavefront kernel: round-robin slicing (slice length: the handle's wave_slice_its)
     const int wslice = (mig && !(a.dbg & 1024)) ? t->wave_slice_its : 0;
     const size_t ycap = wslice > 0 ? (size_t)16 * B + 8192 : 0;
     const size_t off_simd = 32, off_seq = off_simd + (mig ? sizeof(int) * MIG_SIMDS : 0), off_ids = off_seq + cap * 4,
