@@ -8,7 +8,7 @@ G.edges(data=True), number_of_nodes()) are provided as light views.
 """
 import numpy as np
 
-from ..utils.constants import (ABOVE, BASE, BELOW, BOUNDED, DIST, LOWER, OBSTACLE, POS, ROBOT,
+from ..utils.constants import (ABOVE, BASE, BELOW, BOUNDED, DIST, END_EFFECTOR, LOWER, OBSTACLE, POS, ROBOT,
                                TYPE, UPPER, MAIN_PREFIX)
 from ..utils.lie import as_matrix
 
@@ -40,6 +40,18 @@ class _Adj:
         return v in self._g._idx and bool(self._g.edge[self._i, self._g.index(v)])
 
 
+class _Nodes(dict):
+    """graph.nodes: name -> attribute dict, and callable like networkx' NodeView --
+    nodes() lists the names, nodes(data=True) (name, attributes), nodes(data=KEY) (name, value)."""
+
+    def __call__(self, data=False, default=None):
+        if data is False:
+            return list(self)
+        if data is True:
+            return list(self.items())
+        return [(n, a.get(data, default)) for n, a in self.items()]
+
+
 class DistanceGraph:
     planar_bounded = False  # planar graphs store BOUNDED as a plain string (graph_planar.py:108)
 
@@ -53,7 +65,7 @@ class DistanceGraph:
         self.lower = np.full((N, N), np.nan)
         self.upper = np.full((N, N), np.nan)
         self.bounded = np.full((N, N), B_NOEDGE, dtype=np.int8)
-        self.nodes = {n: {} for n in self.node_ids}
+        self.nodes = _Nodes({n: {} for n in self.node_ids})
 
     # -- container protocol ----------------------------------------------------------------------
     def index(self, name):
@@ -105,7 +117,18 @@ class DistanceGraph:
     def _copy_into(self, G):
         for name in ("edge", "dist", "lower", "upper", "bounded"):
             setattr(G, name, getattr(self, name).copy())
-        G.nodes = {n: dict(a) for n, a in self.nodes.items()}
+        G.nodes = _Nodes({n: dict(a) for n, a in self.nodes.items()})
+        return G
+
+    def subgraph(self, names):
+        """The graph induced by `names` (in this graph's node order), as a copy."""
+        keep = [n for n in self.node_ids if n in set(names)]
+        idx = np.array([self._idx[n] for n in keep], dtype=int)
+        G = DistanceGraph(keep, self.dim)
+        G.planar_bounded = self.planar_bounded
+        for name in ("edge", "dist", "lower", "upper", "bounded"):
+            setattr(G, name, getattr(self, name)[np.ix_(idx, idx)].copy())
+        G.nodes = _Nodes({n: dict(self.nodes[n]) for n in keep})
         return G
 
     def positions(self):
@@ -149,6 +172,23 @@ class ProblemGraph(DistanceGraph):
     def structure_nodes(self):
         return self._nodes_of(ROBOT)
 
+    @property
+    def end_effector_nodes(self):
+        """graph_base.py:57-68: the nodes tagged END_EFFECTOR (only ProblemGraphPlanar tags any), cached."""
+        if not hasattr(self, "_end_effector_nodes"):
+            self._end_effector_nodes = self._nodes_of(END_EFFECTOR)
+        return self._end_effector_nodes
+
+    @property
+    def base(self):
+        """graph_base.py:70-75: the base coordinate system's subgraph (a copy; edges are undirected here)."""
+        return self.subgraph(self.base_nodes)
+
+    @property
+    def structure(self):
+        """graph_base.py:77-82: the robot structure's subgraph."""
+        return self.subgraph(self.structure_nodes)
+
     def _instance(self):
         G = DistanceGraph(self.node_ids, self.dim)
         G.planar_bounded = self.planar_bounded
@@ -180,6 +220,11 @@ class ProblemGraph(DistanceGraph):
     def distance_matrix(self):
         from ..utils.dgp import distance_matrix_from_graph
         return distance_matrix_from_graph(self)
+
+    def distance_matrix_from_joints(self, joint_angles):
+        """graph_base.py:129-136: squared distances between all nodes at the given configuration."""
+        from ..utils.dgp import distance_matrix_from_graph
+        return distance_matrix_from_graph(self.realization(joint_angles))
 
     def adjacency_matrix(self):
         from ..utils.dgp import adjacency_matrix_from_graph

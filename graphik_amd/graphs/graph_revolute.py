@@ -155,6 +155,26 @@ class ProblemGraphRevolute(ProblemGraph):
         q = joint_variables_revolute_batch(self, P[None], T_fin)[0]
         return self.robot.array_to_q(q)
 
+    def distance_bounds_from_sampling(self, samples=2000):
+        """graph_revolute.py:325-349: LOWER / UPPER of EVERY node pair from the extremes of
+        distance_matrix_from_joints over random configurations (one np.random.rand() per joint and
+        sample, as the reference draws them).  Kept: DIST is set to |D_max - D_min| -- not to the
+        distance -- where the squared extremes differ by less than 1e-5.  Not kept: the self-loops
+        the reference adds on the diagonal (this graph has no representation for them)."""
+        robot = self.robot
+        D_min = self.distance_matrix_from_joints(robot.random_configuration())
+        D_max = D_min.copy()
+        for _ in range(samples):
+            D = self.distance_matrix_from_joints(robot.random_configuration())
+            np.maximum(D_max, D, out=D_max)
+            np.minimum(D_min, D, out=D_min)
+        ids = self.node_ids
+        for i in range(len(ids)):
+            for j in range(i + 1, len(ids)):
+                rigid = abs(D_max[i, j] - D_min[i, j]) < 1e-5
+                self.set_edge(ids[i], ids[j], lower=np.sqrt(D_min[i, j]), upper=np.sqrt(D_max[i, j]),
+                              dist=abs(D_max[i, j] - D_min[i, j]) if rigid else None)
+
     def get_pose(self, joint_angles, query_node):
         T = self.robot.pose(joint_angles, "p" + query_node[1:])
         return T.dot(trans_axis(self.axis_length, "z")) if query_node[0] == AUX_PREFIX else T

@@ -67,6 +67,19 @@ class Robot:
     def T_base(self):
         return self.nodes[ROOT]["T0"]
 
+    @property
+    def limited_joints(self):
+        """robot_base.py:141-150: joints whose limits a graph could express (set by the graph's set_limits)."""
+        return getattr(self, "_limited_joints", [])
+
+    @limited_joints.setter
+    def limited_joints(self, lim):
+        self._limited_joints = list(lim)
+
+    @property
+    def spherical(self):
+        return False
+
     def random_configuration(self):
         """One np.random.rand() per joint in p1..pn order (robot_base.py:76-85)."""
         q = {}

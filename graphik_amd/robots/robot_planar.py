@@ -39,6 +39,10 @@ class RobotPlanar(Robot):
             T[node] = T[self.parent[node]].dot(SE2(SO2.identity(), np.array([self.l[node], 0.0])))
         return T
 
+    def from_params(self):
+        """robot_planar.py:51-60 (the reference's public name): zero-configuration frames {joint: SE2}."""
+        return self._from_params()
+
     def pose(self, joint_angles, query_node):
         path = self.kinematic_map[ROOT][query_node]
         T = self.nodes[ROOT]["T0"]

@@ -48,6 +48,10 @@ class RobotRevolute(Robot):
             T[node] = acc
         return T
 
+    def from_dh_params(self, params):
+        """robot_revolute.py:53-83 (the reference's public name): zero-configuration frames {joint: SE3}."""
+        return self._from_dh(params)
+
     def pose(self, joint_angles, query_node):
         """T0[root] * prod exp(S_pred * q_cur) * T0[node]  (robot_revolute.py:85-103)."""
         path = self.kinematic_map[ROOT][query_node]

@@ -64,6 +64,23 @@ def graph_from_pos_dict(P, dist=True):
     return graph_from_pos(np.array([P[k] for k in ids]), ids, dist)
 
 
+def graph_complete_edges(G, overwrite=False):
+    """dgp.py:124-147: add the distance between every two nodes with known positions (in place)."""
+    G.complete_edges(overwrite=overwrite)
+    return G
+
+
+def normalize_positions(Y, scale=False):
+    """dgp.py:233-242: centre the points and rotate them into the eigenbasis of their scatter matrix
+    (numpy's eig, in its order and with its signs, as the reference's tests rely on); `scale`
+    multiplies by the largest coordinate magnitude, as the reference does."""
+    Y = np.asarray(Y, dtype=float)
+    Yc = Y - Y.mean(0)
+    _, v = np.linalg.eig(Yc.T.dot(Yc))
+    Ycr = Yc.dot(v)
+    return Ycr * np.abs(Ycr).max() if scale else Ycr
+
+
 def factor(A):
     """eigh, clip negatives, scale columns by sqrt(eigenvalue), flip (dgp.py:150-159)."""
     n = A.shape[0]

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import SCENARIOS, SCENARIOS_3D, load_golden, make_graph
+from conftest import REPO, SCENARIOS, SCENARIOS_3D, load_golden, make_graph
 from graphik_amd.utils import dgp
 from graphik_amd.utils.lie import SE2, SE3
 from graphik_amd.utils.utils import table_environment
@@ -396,3 +396,87 @@ def test_remaining_loaders_match_reference(name):
         assert np.abs(G.positions() - g("X")[s_]).max() < 1e-13
         qr = graph.joint_variables(G, {f"p{n}": T})
         assert np.abs(robot.q_to_array(qr) - g("q_rec")[s_]).max() < 1e-9
+
+
+# ---- the rest of the ProblemGraph surface (graph_base.py:57-137, graph_revolute.py:325-349) ----------
+@pytest.mark.parametrize("name", ["ur10", "planar10"])
+def test_graph_api_members_match_reference(name):
+    """distance_matrix_from_joints, end_effector_nodes, the base / structure subgraphs and the callable
+    nodes view against what the reference's own objects return (tools/capture_golden_api.py)."""
+    d = np.load(os.path.join(REPO, "tests", "golden", "graph_api.npz"))
+    robot, graph = make_graph(name)
+    assert list(graph.node_ids) == list(d[f"{name}_ids"]) == graph.nodes() == list(d[f"{name}_nodes_call"])
+    for q, D in zip(d[f"{name}_q"], d[f"{name}_D"]):
+        got = graph.distance_matrix_from_joints(robot.array_to_q(q))
+        assert np.allclose(got, D, rtol=0, atol=1e-12 * max(1.0, np.abs(D).max()))
+    assert list(graph.end_effector_nodes) == list(d[f"{name}_ee_nodes"])
+    from graphik_amd.utils.constants import TYPE
+    assert ["|".join(t) for _, t in graph.nodes(data=TYPE)] == list(d[f"{name}_types"])
+    assert dict(graph.nodes(data=True)).keys() == dict.fromkeys(graph.node_ids).keys()
+    for sub in ("base", "structure"):
+        S = getattr(graph, sub)
+        assert sorted(S.nodes()) == sorted(d[f"{name}_{sub}_nodes"])     # (networkx filters through a set: its order means nothing)
+        # (the reference's subgraph views are directed; this graph stores undirected edges)
+        want = {frozenset(e.split(">")) for e in d[f"{name}_{sub}_edges"]}
+        assert {frozenset(e) for e in S.edges()} == want
+        u, v = next(iter(S.edges()))
+        assert S[u][v] == graph[u][v]
+
+
+def test_distance_bounds_from_sampling_matches_reference():
+    """graph_revolute.py:325-349 under a fixed numpy seed: the same 2001 random configurations give
+    the same LOWER / UPPER for every node pair, and DIST = |D_max - D_min| on the rigid pairs."""
+    from graphik_amd.utils.constants import DIST, LOWER, UPPER
+    d = np.load(os.path.join(REPO, "tests", "golden", "graph_api.npz"))
+    robot, graph = make_graph("ur10")
+    assert robot.spherical is False and isinstance(robot.limited_joints, list)
+    np.random.seed(11)
+    graph.distance_bounds_from_sampling()
+    ids = graph.node_ids
+    off = ~np.eye(len(ids), dtype=bool)
+    for key, M in ((LOWER, graph.lower), (UPPER, graph.upper)):
+        ref = d[f"ur10_sampled_{key}"]
+        ref = np.where(np.isnan(ref), ref.T, ref)          # (directed there, symmetric here)
+        assert np.allclose(M[off], ref[off], rtol=0, atol=1e-9), key
+    ref = d[f"ur10_sampled_{DIST}"]
+    ref = np.where(np.isnan(ref), ref.T, ref)
+    rigid = np.abs(graph.upper ** 2 - graph.lower ** 2) < 1e-5
+    assert np.all(np.abs(graph.dist[rigid & off]) < 1e-5) and rigid[off].sum() >= 20
+
+
+def test_normalize_positions_and_graph_complete_edges():
+    """dgp.normalize_positions as the reference's joint-variable tests use it (test_joint_variables.py:49):
+    centred, principal axes, invariant under rigid motions up to column signs; graph_complete_edges is the
+    module-level spelling of DistanceGraph.complete_edges."""
+    rs = np.random.RandomState(3)
+    Y = rs.randn(9, 3) * [3.0, 2.0, 0.5]
+    Z = dgp.normalize_positions(Y)
+    assert np.allclose(Z.mean(0), 0, atol=1e-12)
+    C = Z.T.dot(Z)
+    assert np.allclose(C - np.diag(np.diag(C)), 0, atol=1e-9)
+    R, _ = np.linalg.qr(rs.randn(3, 3))
+    Z2 = dgp.normalize_positions(Y.dot(R.T) + [1.0, -2.0, 0.3])
+    # same points in the principal frame: equal up to the order / sign of the axes
+    assert np.allclose(np.sort(np.abs(Z), axis=1), np.sort(np.abs(Z2), axis=1), atol=1e-9)
+    S = dgp.normalize_positions(Y, scale=True)
+    assert np.allclose(S, Z * np.abs(Z).max())
+    robot, graph = make_graph("planar10")
+    G = graph.realization(robot.zero_configuration())
+    D = dgp.distance_matrix_from_graph(dgp.graph_complete_edges(G, overwrite=True))
+    P = dgp.pos_from_graph(G)
+    assert np.allclose(D, ((P[:, None] - P[None]) ** 2).sum(-1), atol=1e-12)
+
+
+def test_reference_spellings_of_the_robot_constructors():
+    """RobotRevolute.from_dh_params / RobotPlanar.from_params under the reference's public names."""
+    robot, _ = make_graph("planar10")
+    T = robot.from_params()
+    assert set(T) == set(robot.joint_ids) and np.allclose(T["p10"].as_matrix()[:2, 2], [10.0, 0.0])
+    from graphik_amd.robots import RobotRevolute
+    n = 3
+    params = {"a": [0.0, 0.5, 0.5], "alpha": [np.pi / 2, 0.0, 0.0], "d": [0.3, 0.0, 0.0], "theta": [0.0, 0.0, 0.0],
+              "modified_dh": False, "num_joints": n, "joint_limits_lower": n * [-np.pi], "joint_limits_upper": n * [np.pi]}
+    r = RobotRevolute(params)
+    T = r.from_dh_params(params)
+    for name in r.joint_ids:
+        assert np.allclose(T[name].as_matrix(), r.nodes[name]["T0"].as_matrix())
