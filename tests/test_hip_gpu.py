@@ -1435,3 +1435,74 @@ def test_planar_tree_solve_batch(torch_cuda, which):
         q = graph.joint_variables(info["x"])
         dq = np.array([q[j] for j in robot.joint_ids[1:]]) - g("sol_q_sol")[s_]
         assert np.abs(np.mod(dq + np.pi, 2 * np.pi) - np.pi).max() < 1e-8
+
+
+def test_c_abi_error_behaviour(torch_cuda):
+    """Every entry point refuses bad arguments with a non-zero return and a message in
+    gik_last_error() -- no crash, no silent success (include/graphik_amd.h; the Python layer turns
+    these into GikError)."""
+    import ctypes as C
+    from graphik_amd import _ffi
+    L = _ffi.lib()
+    ti = np.array([0, 0, 1], dtype=np.int32)           # terms sorted by (i, j, kind)
+    tj = np.array([1, 2, 2], dtype=np.int32)
+    tk = np.full(3, _ffi.TERM_EQ, dtype=np.int32)
+
+    def desc(**kw):
+        d = _ffi.TemplateDesc()
+        L.gik_default_params(C.byref(d))
+        d.N, d.k, d.n_terms = 3, 3, 3
+        d.term_i = ti.ctypes.data_as(C.POINTER(C.c_int32))
+        d.term_j = tj.ctypes.data_as(C.POINTER(C.c_int32))
+        d.term_kind = tk.ctypes.data_as(C.POINTER(C.c_int32))
+        for k_, v in kw.items():
+            setattr(d, k_, v)
+        return d
+
+    def refused(rc, fragment):
+        msg = L.gik_last_error().decode()
+        assert rc != 0 and fragment in msg, (rc, msg)
+
+    h = C.c_void_p()
+    refused(L.gik_template_create(None, C.byref(h)), "null")
+    refused(L.gik_template_create(C.byref(desc(abi_version=_ffi.ABI_VERSION - 1)), C.byref(h)), "ABI")
+    refused(L.gik_template_create(C.byref(desc(k=4)), C.byref(h)), "k must be")
+    refused(L.gik_template_create(C.byref(desc(N=1)), C.byref(h)), "N must be")
+    refused(L.gik_template_create(C.byref(desc(N=129)), C.byref(h)), "N must be")
+    refused(L.gik_template_create(C.byref(desc(n_terms=0)), C.byref(h)), "n_terms")
+    refused(L.gik_template_create(C.byref(desc(solver=7)), C.byref(h)), "solver")
+    refused(L.gik_template_create(C.byref(desc(clique_closed_form=9)), C.byref(h)), "clique_closed_form")
+    bad_j = np.array([1, 2, 1], dtype=np.int32)          # a term from a node to itself
+    d = desc()
+    d.term_j = bad_j.ctypes.data_as(C.POINTER(C.c_int32))
+    refused(L.gik_template_create(C.byref(d), C.byref(h)), "bad term indices")
+    bad_k = np.array([1, 5, 1], dtype=np.int32)
+    d = desc()
+    d.term_kind = bad_k.ctypes.data_as(C.POINTER(C.c_int32))
+    refused(L.gik_template_create(C.byref(d), C.byref(h)), "bad term kind")
+    # a good handle, bad calls on it
+    assert L.gik_template_create(C.byref(desc()), C.byref(h)) == 0
+    Y = torch_cuda.zeros(2, 3, 3, dtype=torch_cuda.float64, device="cuda")
+    tg = torch_cuda.ones(2, 3, dtype=torch_cuda.float64, device="cuda")
+    st = torch_cuda.zeros(2, _ffi.STATS_BYTES // 8, dtype=torch_cuda.float64, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    refused(L.gik_solve_batch(h, None, p(tg), 2, p(Y), p(st), None, None), "null buffer")
+    refused(L.gik_solve_batch(h, p(Y), p(tg), -1, p(Y), p(st), None, None), "bad argument")
+    refused(L.gik_solve_batch(None, p(Y), p(tg), 2, p(Y), p(st), None, None), "bad argument")
+    refused(L.gik_prepare_batch(h, p(Y), 2, p(tg), p(Y), None, None), "no pipeline attached")
+    refused(L.gik_recover_batch(h, p(Y), p(Y), 2, p(Y), p(Y), p(Y), None), "no pipeline attached")
+    refused(L.gik_cost(h, None, p(tg), 2, p(st), None), "null")
+    refused(L.gik_template_get_info(h, None), "null")
+    refused(L.gik_pipeline_attach(h, None), "null")
+    assert L.gik_solve_batch(h, p(Y), p(tg), 0, p(Y), p(st), None, None) == 0      # an empty batch is not an error
+    L.gik_template_destroy(h)
+    L.gik_template_destroy(None)                                                    # and destroying nothing is harmless
+    # the Python layer: unknown parameters and solvers are refused before the library is called
+    d0 = load_golden("lwa4d")
+    with pytest.raises(KeyError):
+        _template(d0, no_such_parameter=1)
+    from graphik_amd.engine import Template
+    with pytest.raises(ValueError):
+        Template.from_matrices(d0["omega"], d0["psi_L"], d0["psi_U"], k=3, use_limits=True, params={"solver": "Newton"})
+    with pytest.raises(_ffi.GikError):
+        Template.from_matrices(d0["omega"], k=5, use_limits=False)
