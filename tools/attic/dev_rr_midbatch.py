@@ -6,7 +6,7 @@ sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, torch
 from graphik_amd.solvers.riemannian_solver import BatchProblem
 from conftest import make_graph
-cfgs = (("1w", {"debug_flags": 512}), ("2w+spread", {"waves_per_cu": 8, "debug_flags": 1024}), ("2w+spread+rr", {"waves_per_cu": 8}))
+cfgs = (("1w", {"waves_per_cu": 4, "debug_flags": 512}), ("2w+spread", {"waves_per_cu": 8, "debug_flags": 1024}), ("2w+spread+rr", {"waves_per_cu": 8}))
 for name, B in [tuple(x.split(":")) for x in os.environ.get("CASES", "lwa4d:4096 kuka:4096 ur10:4096 lwa4d:2048 lwa4d:3000 kuka:6144").split()]:
     B = int(B)
     robot, graph = make_graph(name)
