@@ -18,9 +18,11 @@
 #include <vector>
 
 #include "gik_block.hip.h"
+#include "gik_npt.hip.h"
 #include "gik_prep.hip.h"
 #include "gik_rcg.hip.h"
 #include "gik_rtr.hip.h"
+#include "gik_rtrv.hip.h"
 #include "gik_wave.hip.h"
 #include "graphik_amd.h"
 
@@ -139,6 +141,7 @@ struct SolveArgs {
   unsigned int *q_seq;             // [cap], 0xffffffff = not published
   SliceState *q_state;             // [B]
   BlockTabs bt;                    // workgroup-per-problem path
+  NptTabs nt;                      // node-per-lane path (rtr_npt_kernel)
 };
 
 // This wave's physical SIMD: XCC_ID[3:0] and the SIMD / CU / SH / SE fields of HW_ID (bits 4-5 and
@@ -478,6 +481,7 @@ struct KatArgs {
   int planar_proj_exact;
   AnchArgs an;
   BlockTabs bt;
+  NptTabs nt;
 };
 
 template <int K, int MAXDEG, bool ANCH = false>
@@ -690,6 +694,162 @@ __global__ void __launch_bounds__(BLOCK_NT) kat_block_kernel(KatArgs a, int SL) 
   }
   if (cx.active) a.out[at] = res;
 }
+
+// ------------------------------------------------------------------------------------------
+// node-per-lane variants (graphs with N*k > 64, k = 3): a lane owns whole graph nodes with all their
+// components (gik_npt.hip.h), driver over a small vector per thread (gik_rtrv.hip.h).  <TL, 1, 2>: one
+// node per lane, two wavefronts (128 threads) per problem; <TL, 2, 1>: two nodes per lane, one
+// wavefront per problem.  Persistent; problems are claimed from the same ticket counter / re-queue
+// ring as the workgroup kernel's (FIFO time slicing: the long problems, unknown in advance, must
+// not be the last to START).  LDS-bound at three problems per CU on the table scene.
+template <int TL, int NS, int NW>
+__global__ void __launch_bounds__(WAVE * NW, 1) rtr_npt_kernel(SolveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int sh_claim[2];
+  using Ctx = NptCtx<TL, NS, NW>;
+  const int tid = threadIdx.x;
+  const int NK = a.N * 3;
+  Ctx cx;
+  cx.init(a.nt, smem);
+  int pass = 0;
+  for (;;) {
+    int b = 0, resumed = 0;
+    if (a.dbg & 1) {      // static block -> problem map (keeps the claim below a scalar-branch loop, see rcg_wave_kernel)
+      b = (int)blockIdx.x + pass * (int)gridDim.x;
+      ++pass;
+      if (b >= a.B) b = -1;
+    } else if constexpr (NW == 1) {
+      if (tid == 0) b = claim_work(a.work_counter, a.q_seq, a.q_ids, a.q_done, a.B, a.slice_its > 0, resumed);
+      b = __builtin_amdgcn_readlane(b, 0);
+      resumed = __builtin_amdgcn_readlane(resumed, 0);
+    } else {
+      if (tid == 0) {
+        int res = 0;
+        sh_claim[0] = claim_work(a.work_counter, a.q_seq, a.q_ids, a.q_done, a.B, a.slice_its > 0, res);
+        sh_claim[1] = res;
+      }
+      __syncthreads();
+      b = __builtin_amdgcn_readfirstlane(sh_claim[0]);
+      resumed = __builtin_amdgcn_readfirstlane(sh_claim[1]);
+      __syncthreads();
+    }
+    if (UNI(b < 0)) break;
+    cx.load_problem(a.targets + (size_t)b * a.T, a.nt);
+    // (unconditional load of the resume state from a zeroed array: a conditional one makes the solver's
+    // counters divergent -- NOTEBOOK 8.3)
+    RtrResume rs = {0.0, 0, 0, 0, 0, 0, 0};
+    if (a.slice_its > 0) {
+      rs = load_slice_state(&a.q_state[b]);
+      rs.resumed = resumed;
+    }
+    const double *src = resumed ? a.Y_out : a.Y_init;
+    double x[Ctx::NE];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        x[3 * s + q] = cx.live[s] ? __builtin_nontemporal_load(&src[(size_t)b * NK + cx.gnode[s] * 3 + q]) : 0.0;
+    RtrOut ro;
+    rtr_solve_vec<true, true>(cx, a.p, a.trace, a.has_trace, a.dbg, a.dbg_buf, b, x, ro, rs, a.slice_its);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (cx.live[s]) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a.Y_out[(size_t)b * NK + cx.gnode[s] * 3 + q] = x[3 * s + q];
+      }
+    if (UNI(ro.paused)) {
+      if (tid == 0) {
+        SliceState st;
+        st.Delta = ro.Delta;
+        st.kiter = ro.iterations;
+        st.inner_total = ro.inner_total;
+        st.inner_exec = ro.inner_executed;
+        st.n_accept = ro.n_accept;
+        st.resumes = rs.resumes + 1;
+        st.pad = 0;
+        a.q_state[b] = st;
+      }
+      __threadfence();
+      Ctx::block_sync();
+      if (tid == 0) requeue_work(a.q_tail, a.q_ids, a.q_seq, a.B, b);
+      continue;
+    }
+    if (tid == 0) {
+      gik_stats s;
+      s.f = ro.f;
+      s.gradnorm = ro.gradnorm;
+      s.iterations = ro.iterations;
+      s.inner_total = ro.inner_total;
+      s.stop = ro.stop;
+      s.n_accept = ro.n_accept;
+      s.inner_executed = ro.inner_executed;
+      s.flags = cx.lowrank ? 1 : 0;
+      s.stepsize = ro.Delta;
+      a.stats[b] = s;
+      if (a.slice_its > 0) __hip_atomic_fetch_add(a.q_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int TL, int NS, int NW>
+__global__ void __launch_bounds__(WAVE * NW, 1) kat_npt_kernel(KatArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using Ctx = NptCtx<TL, NS, NW>;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const int NK = a.N * 3;
+  Ctx cx;
+  cx.init(a.nt, smem);
+  cx.load_problem(a.targets ? a.targets + (size_t)b * a.T : nullptr, a.nt);
+  double y[Ctx::NE], w[Ctx::NE], res[Ctx::NE];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const size_t at = (size_t)b * NK + (cx.live[s] ? cx.gnode[s] : 0) * 3 + q;
+      y[3 * s + q] = cx.live[s] ? a.Y[at] : 0.0;
+      w[3 * s + q] = (a.W && cx.live[s]) ? a.W[at] : 0.0;
+      res[3 * s + q] = 0.0;
+    }
+  const double f = cx.cost(y);
+  if (a.mode == 0) {
+    if (tid == 0) a.out[b] = f;
+    return;
+  }
+  if (a.mode == 4 && tid == 0) a.out_f[b] = f;
+  cx.commit(y, res);
+  if (a.mode == 2) {
+    cx.ehess(w, res);
+  } else if (a.mode == 3) {     // PSDFixedRank.proj: Z - Q Q^T Z
+    cx.proj_setup(y);
+    double v[3], u[3];
+    cx.vert_dots(w, v[0], v[1], v[2]);
+    cx.template sum_n<3>(v);
+    cx.vert_coords(v, u);
+    cx.vert_apply(u, w, res);
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    if (cx.live[s]) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a.out[(size_t)b * NK + cx.gnode[s] * 3 + q] = res[3 * s + q];
+    }
+}
+
+// the compiled node-per-lane variants
+struct NptVariant {
+  int TL, NW;
+  void (*solve)(SolveArgs);
+  void (*kat)(KatArgs);
+  size_t (*lds)(int, int, int, int);
+};
+template <int TL, int NS, int NW>
+static size_t npt_lds_of(int n_pairs, int n_wrows, int n_rows, int n_terms) {
+  return NptCtx<TL, NS, NW>::lds_bytes(n_pairs, n_wrows, n_rows, n_terms);
+}
+#define GIK_NPT_VARIANT(TL, NS, NW) {TL, NW, rtr_npt_kernel<TL, NS, NW>, kat_npt_kernel<TL, NS, NW>, npt_lds_of<TL, NS, NW>}
+static const NptVariant kNptVariants[] = {GIK_NPT_VARIANT(1, 1, 2), GIK_NPT_VARIANT(4, 1, 2), GIK_NPT_VARIANT(1, 2, 1),
+                                          GIK_NPT_VARIANT(4, 2, 1)};
 
 // ------------------------------------------------------------------------------------------
 // developer micro-benchmark: per-component cycle cost of one wavefront.  Only in the -DGIK_DEV
@@ -996,6 +1156,13 @@ struct gik_template {
   int SL;         // slots per thread on the block path
   int SLE;        // ... of which the first SLE hold equality terms (or padding) only
   gik::BlockTabs bt = {nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0};
+  // node-per-lane path (rtr_npt_kernel): trust-region solves and the known-answer entry points of
+  // 3-D graphs beyond one wavefront's 64 unknowns; the workgroup tables above stay (ConjugateGradient)
+  bool is_npt = false;
+  gik::NptTabs nt = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const gik::NptVariant *npt_variant = nullptr;
+  size_t npt_smem = 0;
+  int npt_waves_per_cu = 1;
   // device pre/post-processing (gik_pipeline_attach)
   bool has_pipe;
   gik::PipeConst pc;
@@ -1158,6 +1325,19 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   int n_clq = 0, Tc = T;
   std::vector<int> nc_term, clq_term, clq_pair_term, node_of_row(BLOCK_MAXN, -1), wave_sl(2 * BLOCK_WAVES, 0);
   std::vector<unsigned short> clq_pid;   // [M][512] compact pair id per (thread, partner), 0xffff = none
+  // node-per-lane path: 3-D graphs beyond one wavefront, trust-region solver, theta = 1.
+  // force_block_path: 0 = automatic, 1 = the workgroup kernels, 2 = the node-per-lane kernel
+  if (d->force_block_path == 2) is_block = true;
+  const bool npt_wanted = is_block && d->k == 3 && d->solver == GIK_SOLVER_TRUST_REGIONS && d->theta == 1.0 && !ad &&
+                          (d->force_block_path == 2 ||
+                           (d->force_block_path == 0 && d->N * d->k > WAVE && !getenv("GIK_NO_NPT")));   // (developer A/B switch, read once)
+  bool npt_ok = false;
+  const bool npt_two_waves = !(dbg_eff & 2048);      // 2048: one wavefront per problem, two nodes per lane
+  int npt_TL = 1, npt_DEG0 = 0, npt_DEG1 = 0, npt_n_wrows = 0, npt_cbase = 0, npt_n_rows = 0, npt_n_terms = 0, npt_term_sync = 0;
+  std::vector<int> npt_node_of_row, npt_term_tgt, npt_pair_term;
+  std::vector<uint32_t> npt_term_rec;
+  std::vector<unsigned short> npt_gather;
+  std::vector<unsigned char> npt_wslot;
   if (is_block) {
     // A rigid clique -- a set of nodes every pair of which is tied by an equality term (the
     // anchors of a scene with many obstacles) -- is taken out of the slot tables and handled in
@@ -1288,6 +1468,121 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
         if (e < (int)src.size()) m = meta_pack(src[e].j, src[e].term, src[e].kind, src[e].owner);
         meta[(size_t)s * BLOCK_NT + tid] = m;
       }
+    }
+
+    // ---- node-per-lane tables (NptTabs, gik_npt.hip.h) ----
+    // Two layouts.  Two wavefronts per problem, one node per lane (default): the nodes outside the
+    // clique take the first rows, then the clique's nodes, those that carry slot terms first -- every
+    // end node of a slot term then sits in wavefront 0, which evaluates the terms, and the
+    // direction / term tables need no barrier of their own.  One wavefront, two nodes per lane
+    // (debug_flags 2048): the clique's nodes take rows 0..n_clq-1, the others follow; nodes that carry
+    // slot terms go to EVEN rows where possible, so that a lane's second node has few or none (its
+    // gather list is as long as the busiest second node's).
+    if (npt_wanted) {
+      const int NSn = npt_two_waves ? 1 : 2, NTn = npt_two_waves ? 2 * WAVE : WAVE;
+      std::vector<int> sdeg(N, 0);
+      for (int t : nc_term) {
+        ++sdeg[d->term_i[t]];
+        ++sdeg[d->term_j[t]];
+      }
+      std::vector<int> cl_busy, cl_idle, others;
+      for (int i = 0; i < N; ++i) {
+        if (in_clq[i]) (sdeg[i] ? cl_busy : cl_idle).push_back(i);
+        else others.push_back(i);
+      }
+      auto by_deg = [&](int a, int b) { return sdeg[a] > sdeg[b]; };
+      std::stable_sort(cl_busy.begin(), cl_busy.end(), by_deg);
+      std::stable_sort(others.begin(), others.end(), by_deg);
+      npt_node_of_row.assign(NPT_MAXN, -1);
+      std::vector<int> nrow(N, -1);
+      int n_rows = 0;
+      if (npt_two_waves) {
+        npt_cbase = (int)others.size();
+        int r = 0;
+        for (int v : others) { npt_node_of_row[r] = v; nrow[v] = r++; }
+        for (int v : cl_busy) { npt_node_of_row[r] = v; nrow[v] = r++; }
+        for (int v : cl_idle) { npt_node_of_row[r] = v; nrow[v] = r++; }
+        n_rows = r;
+      } else {
+        npt_cbase = 0;
+        size_t ib = 0, ii = 0;
+        for (int r = 0; r < n_clq; ++r) {
+          const bool want_busy = (r & 1) == 0;
+          int v;
+          if ((want_busy && ib < cl_busy.size()) || ii >= cl_idle.size()) v = cl_busy[ib++];
+          else v = cl_idle[ii++];
+          npt_node_of_row[r] = v;
+          nrow[v] = r;
+        }
+        const int start = (n_clq + 1) & ~1;
+        const bool even_only = others.empty() || start + 2 * ((int)others.size() - 1) < NPT_MAXN;
+        n_rows = n_clq;
+        for (size_t q = 0; q < others.size(); ++q) {
+          const int r = even_only ? start + 2 * (int)q : n_clq + (int)q;
+          npt_node_of_row[r] = others[q];
+          nrow[others[q]] = r;
+          n_rows = r + 1;
+        }
+      }
+      npt_n_rows = (n_rows + 1) & ~1;
+      // compact direction table: one row per node that carries slot terms
+      npt_wslot.assign(NPT_MAXN, 255);
+      int n_wrows = 0;
+      npt_term_sync = 0;
+      for (int r = 0; r < NPT_MAXN; ++r)
+        if (npt_node_of_row[r] >= 0 && sdeg[npt_node_of_row[r]]) {
+          npt_wslot[r] = (unsigned char)n_wrows++;
+          if (npt_two_waves && r >= WAVE) npt_term_sync = 1;
+        }
+      const int Tn = (int)nc_term.size();
+      const int TLn = Tn <= 64 ? 1 : 4;
+      npt_ok = Tn <= 64 * 4 && n_wrows <= 127;
+      bool npt_lists_fit = true;
+      if (npt_ok) {
+        npt_TL = TLn;
+        npt_term_rec.assign((size_t)TLn * WAVE, 0u);
+        npt_term_tgt.assign((size_t)TLn * WAVE, -1);
+        for (size_t q = 0; q < npt_term_rec.size(); ++q)   // padding: rows 0 / 0, kind 0, the zero direction row
+          npt_term_rec[q] = ((uint32_t)n_wrows << 18) | ((uint32_t)n_wrows << 25);
+        struct GEnt { int other, kind, slot, neg; };
+        std::vector<std::vector<GEnt>> glist(NPT_MAXN);
+        for (int q = 0; q < Tn; ++q) {
+          const int t = nc_term[q], i = d->term_i[t], j = d->term_j[t], kind = d->term_kind[t];
+          const int ri = nrow[i], rj = nrow[j];
+          npt_term_rec[q] = (uint32_t)ri | ((uint32_t)rj << 8) | ((uint32_t)kind << 16) |
+                            ((uint32_t)npt_wslot[ri] << 18) | ((uint32_t)npt_wslot[rj] << 25);
+          npt_term_tgt[q] = t;
+          // term slot q = u * 64 + lane: the order of nc_term (= the reference's edge order)
+          glist[ri].push_back({j, kind, q, 0});
+          glist[rj].push_back({i, kind, q, 1});
+        }
+        int deg[2] = {0, 0};
+        for (int r = 0; r < NPT_MAXN; ++r) {
+          std::stable_sort(glist[r].begin(), glist[r].end(), [](const GEnt &a, const GEnt &b) {
+            return a.other != b.other ? a.other < b.other : a.kind < b.kind;
+          });
+          const int sl = NSn == 1 ? 0 : (r & 1);
+          deg[sl] = std::max(deg[sl], (int)glist[r].size());
+        }
+        npt_DEG0 = deg[0];
+        npt_DEG1 = deg[1];
+        npt_lists_fit = deg[0] + deg[1] <= 16;      // NptCtx::NG packed words
+        const unsigned short pad = (unsigned short)(2 * Tn);
+        npt_gather.assign((size_t)std::max(1, deg[0] + deg[1]) * NTn, pad);
+        for (int r = 0; r < NPT_MAXN; ++r) {
+          const int thr = r / NSn, sl = r % NSn;
+          for (size_t e = 0; e < glist[r].size(); ++e)
+            npt_gather[(size_t)(sl ? deg[0] + (int)e : (int)e) * NTn + thr] =
+                (unsigned short)((glist[r][e].slot << 1) | glist[r][e].neg);
+        }
+        npt_pair_term.clear();
+        for (int a = 0; a < n_clq; ++a)
+          for (int b = a + 1; b < n_clq; ++b)
+            npt_pair_term.push_back(eqterm[(size_t)npt_node_of_row[npt_cbase + a] * N + npt_node_of_row[npt_cbase + b]]);
+        npt_n_wrows = n_wrows;
+        npt_n_terms = Tn;
+      }
+      npt_ok = npt_ok && npt_lists_fit;
     }
   } else {
   MD = var->maxdeg;
@@ -1463,6 +1758,54 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
       return fail("device upload of the workgroup-path tables failed");
     }
   }
+  if (d->force_block_path == 2 && !npt_ok) {
+    gik_template_destroy(t);
+    return fail("node-per-lane kernel: k = 3, TrustRegions, theta = 1, at most 256 terms outside the rigid clique, at most 16 per lane");
+  }
+  if (npt_ok) {
+    bool ok = true;
+    t->nt.node_of_row = upload(t, npt_node_of_row.data(), npt_node_of_row.size(), ok);
+    t->nt.clq_pair_term = upload(t, npt_pair_term.data(), npt_pair_term.size(), ok);
+    t->nt.term_rec = upload(t, npt_term_rec.data(), npt_term_rec.size(), ok);
+    t->nt.term_tgt = upload(t, npt_term_tgt.data(), npt_term_tgt.size(), ok);
+    t->nt.gather = upload(t, npt_gather.data(), npt_gather.size(), ok);
+    t->nt.wslot_of_row = upload(t, npt_wslot.data(), npt_wslot.size(), ok);
+    t->nt.n_clq = n_clq;
+    t->nt.n_pairs = (int)npt_pair_term.size();
+    t->nt.DEG0 = npt_DEG0;
+    t->nt.DEG1 = npt_DEG1;
+    t->nt.n_wrows = npt_n_wrows;
+    t->nt.TL = npt_TL;
+    t->nt.clq_euclid = t->bt.clq_euclid;
+    t->nt.cbase = npt_cbase;
+    t->nt.n_rows = npt_n_rows;
+    t->nt.n_terms = npt_n_terms;
+    t->nt.term_sync = npt_term_sync;
+    for (const NptVariant &v : kNptVariants)
+      if (v.TL == npt_TL && v.NW == (npt_two_waves ? 2 : 1)) t->npt_variant = &v;
+    t->npt_smem = t->npt_variant->lds(t->nt.n_pairs, npt_n_wrows, npt_n_rows, npt_n_terms);
+    const void *fns[2] = {(const void *)t->npt_variant->solve, (const void *)t->npt_variant->kat};
+    int occ_npt = 0;
+    ok = ok && t->npt_smem <= 160 * 1024;
+    if (ok && t->npt_smem > 48 * 1024)
+      for (const void *fn : fns) ok = ok && raise_dynamic_lds(fn, t->npt_smem) == hipSuccess;
+    ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_npt, fns[0], WAVE * t->npt_variant->NW, t->npt_smem) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      if (d->force_block_path == 2) {
+        gik_template_destroy(t);
+        return fail("node-per-lane kernel: device setup failed (LDS)");
+      }
+    } else {
+      t->is_npt = true;
+      t->npt_waves_per_cu = std::max(1, std::min(occ_npt, 4));   // problems (workgroups) per CU
+    }
+  }
+  if ((t->dbg & 32) && t->is_npt)
+    fprintf(stderr, "  node-per-lane kernel: %d wavefront(s) per problem, TL=%d, %d slot terms (sync %d), %d direction rows, gather lists %d + %d, "
+            "clique rows from %d, lds=%zu B, %d problems per CU\n",
+            t->npt_variant->NW, t->nt.TL, t->nt.n_terms, t->nt.term_sync, t->nt.n_wrows, t->nt.DEG0, t->nt.DEG1, t->nt.cbase,
+            t->npt_smem, t->npt_waves_per_cu);
   if (t->dbg & 32)
       fprintf(stderr, "gik_template_create: N=%d k=%d T=%d %s maxdeg=%d lds=%zu B occupancy=%d per CU, %d CUs; "
               "clique %d, slot terms %d, slots %d\n",
@@ -1785,7 +2128,10 @@ static int launch_kat(const gik_template *t, int mode, const double *d_Y, const 
     HIP_OK(hipGetLastError());
     return 0;
   }
-  if (t->is_block) {
+  if (t->is_npt) {
+    a.nt = t->nt;
+    hipLaunchKernelGGL(t->npt_variant->kat, dim3(B), dim3(WAVE * t->npt_variant->NW), t->npt_smem, (hipStream_t)stream, a);
+  } else if (t->is_block) {
     if (t->K == 3)
       hipLaunchKernelGGL(kat_block_kernel<3>, dim3(B), dim3(BLOCK_NT), t->smem_bytes,
                          (hipStream_t)stream, a, t->SL);
@@ -1887,7 +2233,7 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   // Small batches still get one wave per SIMD: their time is the run time of the few problems that
   // go to maxiter, and two of THOSE on one SIMD (equal priority) slow each other down -- at 4096
   // LWA4D goals a third of the launches drew such a pair (128 instead of 116 ms).
-  int wpc = t->waves_per_cu;
+  int wpc = t->is_npt ? t->npt_waves_per_cu : t->waves_per_cu;
   if (!t->is_block && t->K == 3 && wpc > 4 && (long long)B <= 6LL * 4 * t->n_cu) wpc = 4;
   if (t->wpc_override > 0) wpc = t->wpc_override;
   const int grid = std::min(B, t->n_cu * wpc);
@@ -1955,10 +2301,13 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     if (mig) { a.slice_its = wslice; a.slice_cycles = t->wave_slice_cycles; }
     HIP_OK(hipMemsetAsync(base, 0, off_seq, (hipStream_t)stream));
     HIP_OK(hipMemsetAsync(a.q_seq, 0xFF, cap * 4, (hipStream_t)stream));
-    if (mig) HIP_OK(hipMemsetAsync(a.q_state, 0, (size_t)B * sizeof(SliceState), (hipStream_t)stream));
+    if (mig || t->is_npt) HIP_OK(hipMemsetAsync(a.q_state, 0, (size_t)B * sizeof(SliceState), (hipStream_t)stream));
     if (ycap) HIP_OK(hipMemsetAsync(a.y_seq, 0, ycap * 4, (hipStream_t)stream));
   }
-  if (t->is_block) {
+  if (t->is_npt) {
+    a.nt = t->nt;
+    hipLaunchKernelGGL(t->npt_variant->solve, dim3(grid), dim3(WAVE * t->npt_variant->NW), t->npt_smem, (hipStream_t)stream, a);
+  } else if (t->is_block) {
     void (*kern)(SolveArgs, int) =
         cg ? (t->K == 3 ? rcg_block_kernel<3> : rcg_block_kernel<2>)
            : (t->K == 3 ? rtr_block_kernel<3> : rtr_block_kernel<2>);
@@ -1995,6 +2344,11 @@ int gik_template_get_info(const gik_template *t, gik_template_info *info) {
   info->anchored = t->anchored ? 1 : 0;
   info->has_pipeline = t->has_pipe ? 1 : 0;
   info->prepare_is_block = t->prep_block ? 1 : 0;
+  info->node_per_lane = t->is_npt ? 1 : 0;
+  if (t->is_npt) {
+    info->waves_per_cu = t->npt_waves_per_cu;
+    info->lds_bytes = (int32_t)t->npt_smem;
+  }
   return 0;
 }
 

@@ -66,7 +66,11 @@ typedef struct {
   double rho_prime;      /* 0.1                                                           */
   double rho_regularization; /* 1e3                                                       */
   int32_t planar_proj_exact; /* 0: reproduce fixed_rank_psd_sym.py:107-110 literally (k=2) */
-  int32_t force_block_path;  /* 1: use the workgroup-per-problem kernels even if N*k <= 64   */
+  int32_t force_block_path;  /* graphs with N*k > 64 (or a node busier than any wavefront variant) leave the
+                                one-unknown-per-lane kernel; 0: automatic (k = 3, N*k > 64, TrustRegions: the
+                                node-per-lane wavefront kernel, else the workgroup kernels), 1: the
+                                workgroup-per-problem kernels even if N*k <= 64, 2: the node-per-lane kernel
+                                (k = 3, TrustRegions, theta = 1, <= 256 terms outside a rigid clique)        */
   /* scheduling knobs, fixed for the life of the handle (results never depend on them; the
    * environment variables GIK_WAVES_PER_CU / GIK_SLICE / GIK_DBG are read ONCE, at
    * gik_template_create, as developer overrides of these fields)                             */
@@ -189,7 +193,9 @@ typedef struct {
   int32_t anchored;
   int32_t has_pipeline;
   int32_t prepare_is_block;    /* workgroup-per-goal prepare kernel                                 */
-  int32_t reserved[4];
+  int32_t node_per_lane;       /* 1: is_block graphs solved by the node-per-lane wavefront kernel (one wave per
+                                  problem, two nodes per lane) instead of the 512-thread workgroup kernel  */
+  int32_t reserved[3];
 } gik_template_info;
 int gik_template_get_info(const gik_template *t, gik_template_info *info);
 
