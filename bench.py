@@ -214,8 +214,14 @@ def executed_flops(N, k, T, info, lowrank_frac, n_inner, n_outer, n_accept):
     if n == 0:
         return algorithmic_flops(N, k, T, n_inner, n_outer, n_accept)
     T_rest = int(info["n_slot_terms"])
-    hv_low = 12 * k * T_rest + 27 * 2 * n + 58 * 3 * n
-    hv_dense = 12 * k * T_rest + 18 * 2 * n + 49 * 3 * n + 2 * n * 3 * n
+    if info.get("node_per_lane"):
+        # node-per-lane kernel (gik_npt.hip.h): every slot term once (12 k, as the reference's edge loop),
+        # 24 moments (15 without Euclidean targets), ~110 (83) flops of closed form per clique NODE
+        hv_low = 12 * k * T_rest + 24 * 2 * n + 110 * n
+        hv_dense = 12 * k * T_rest + 15 * 2 * n + 83 * n + 2 * n * 3 * n
+    else:
+        hv_low = 12 * k * T_rest + 27 * 2 * n + 58 * 3 * n
+        hv_dense = 12 * k * T_rest + 18 * 2 * n + 49 * 3 * n + 2 * n * 3 * n
     hv = lowrank_frac * hv_low + (1.0 - lowrank_frac) * hv_dense
     F_hv = hv + (4 * N * k * k + k * k + 2 * k ** 4) + 16 * N * k
     F_cost = (3 * k + 6) * T + 5 * N * k
@@ -418,6 +424,13 @@ class Bench:
         flops = algorithmic_flops(N, k, T, exec_local, outer_local, acc_local)   # executed products only
         achieved_tf = flops / (kernel_ms * 1e-3) / 1e12
         info = getattr(prob.template if anch is None else anch.template, "info", None)
+        # which solve kernel the library chose (gik_template_get_info), not a re-derivation of its rules
+        if info and info.get("node_per_lane"):
+            kernel_name = "rtr_npt_kernel (node per lane, %d wavefront(s) per problem)" % int(info["node_per_lane"])
+        elif info and info.get("is_block"):
+            kernel_name = f"rtr_block_kernel<{k}>"
+        else:
+            kernel_name = f"rtr_wave_kernel<{k},{info['max_terms_per_node'] if info else prob.template.maxdeg}>"
         flops_exec = executed_flops(N, k, T, info if anch is None else None, lowrank_local,
                                     exec_local, outer_local, acc_local)
         executed_tf = flops_exec / (kernel_ms * 1e-3) / 1e12
@@ -456,8 +469,7 @@ class Bench:
             "roofline": {"bound": "fp64-valu", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
                          "frac_executed": executed_tf / FP64_PEAK_TFLOPS, "traffic": None,
-                         "kernel": (f"rtr_wave_kernel<{k},{prob.template.maxdeg}>" if N * k <= 64
-                                    else f"rtr_block_kernel<{k}>"), "kernel_ms": kernel_ms, "kernel_ms_per_step": ks,
+                         "kernel": kernel_name, "kernel_ms": kernel_ms, "kernel_ms_per_step": ks,
                          "kernel_share_of_step": kernel_ms / (dt_local / steps * 1e3),
                          "flops_per_launch": flops, "flops_executed_per_launch": flops_exec,
                          "note": "fp64 vector ALU (the contract's \"mfma\" class: compute-bound, not HBM); "
@@ -465,8 +477,8 @@ class Bench:
                                  "rate of one wavefront per problem (and, at this batch size, by the "
                                  "slowest problem), not by HBM or MFMA (SURVEY 8(d), DESIGN 4.1); "
                                  "peak = MI355X fp64 vector/matrix spec"
-                                 + ("" if N * k <= 64 else
-                                    "; workgroup-per-problem kernel: `achieved` / `frac` use the ALGORITHMIC "
+                                 + ("" if not (info and info.get("is_block")) else
+                                    "; graphs beyond one wavefront: `achieved` / `frac` use the ALGORITHMIC "
                                     "flop count of SURVEY 8(d) (12 k |E| per product); a rigid anchor clique "
                                     "is evaluated in closed form with far fewer operations -- "
                                     "`frac_executed` prices the flops the kernel actually executes "
@@ -481,7 +493,7 @@ class Bench:
             out["serving"] = serving
         # HBM traffic of the solve kernel from the PMC passes of the SAME workload (tools/profile.sh:
         # rocprofv3 cannot run inside this process), newest round first; null for unprofiled workloads
-        tags = {("lwa4d", 4096): ["r03", "r02"], ("ur10_table", 4096): ["r03_c3", "r02_block"],
+        tags = {("lwa4d", 4096): ["r04", "r03", "r02"], ("ur10_table", 4096): ["r04_c3"],
                 ("kuka", 65536): ["r03_c4"], ("kuka", 8192): ["r03_c4share"], ("planar10", 65536): ["r03_c5", "r02_c5"]}
         for tag in ([] if intended else tags.get((robot_name, B), [])):
             traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json" if tag == "r02" else f"{tag}_hbm_traffic.json")

@@ -94,7 +94,7 @@ def build(force=False, verbose=False):
 
 
 def build_dev(force=False, verbose=False):
-    extra = ("-DGIK_DEV",)
+    extra = ("-DGIK_DEV", "-DGIK_NPT_PROF")
     if not force and not _stale(DEV_LIB, extra):
         return DEV_LIB
     return _compile(DEV_LIB, extra, verbose, force)

@@ -140,6 +140,13 @@ struct NptCtx {
   double yc[NS][3];
   double L_i00, L_l10, L_l20, L_i11, L_l21, L_i22;
   double ck[4][NE];          // tCG checkpoint (register file)
+#ifdef GIK_NPT_PROF
+  long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // developer build: cycles per phase of a product (wavefront 0 of problem 0)
+  __device__ inline long long pf_now() const { return (long long)__builtin_readcyclecounter(); }
+#define NPT_PF(i, t_prev) { const long long t_ = pf_now(); pf[i] += t_ - t_prev; t_prev = t_; }
+#else
+#define NPT_PF(i, t_prev)
+#endif
 
   __host__ __device__ static constexpr size_t lds_bytes(int n_pairs, int n_wrows, int n_rows, int n_terms) {
     return sizeof(double) * ((size_t)n_rows * NPT_RS + (size_t)(n_wrows + 1) * NPT_RS +
@@ -198,16 +205,24 @@ struct NptCtx {
     sum_n<1>(v);
     return v[0];
   }
-  // the 24 moment totals of ehess(), distributed (value q in lane npt_lane_of(q) and its neighbour)
-  __device__ inline double sum24(double (&v)[24]) {
-    double tot = wave_sum24_distributed(v);
+  // the 24 moment totals of ehess(), distributed (value q in lane npt_lane_of(q) and its neighbour).
+  // Two wavefronts: publish the wavefront's totals, then -- behind work that does not depend on them --
+  // sum24_finish() adds the other wavefront's (wavefront order: the same bits in both).
+  __device__ inline void sum24_publish(double tot) {
     if constexpr (NW > 1) {
       double *buf = sh_red + red_buf * (NW * 32);
       const int q = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) |
                     (((lane >> 1) & 1) << 4);
       buf[wave * 32 + q] = tot;        // (both lanes of a pair store the same value)
+    }
+  }
+  __device__ inline double sum24_finish(double tot) {
+    if constexpr (NW > 1) {
+      const double *buf = sh_red + red_buf * (NW * 32);
+      const int q = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) |
+                    (((lane >> 1) & 1) << 4);
       __syncthreads();
-      tot = buf[q] + buf[32 + q];      // wavefront order: the same bits in both wavefronts
+      tot = buf[q] + buf[32 + q];
       red_buf ^= 1;
     }
     return tot;
@@ -572,30 +587,47 @@ struct NptCtx {
   // +-t table per word; list lengths are uniform bounds.
   __device__ inline void gather_terms(double (&acc)[NS][3]) const {
     const int n0 = DEG0, n = DEG0 + DEG1;
-    // groups of four entries behind ONE uniform test each: the eight LDS reads of a group are in flight
-    // together (a test per entry serialises their latencies: nine round trips instead of three)
+    // Groups of GG entries behind ONE uniform test each; the LDS reads of ALL groups are issued before
+    // the first sum (a test per entry serialises their latencies -- measured nine round trips instead
+    // of one; a DS instruction costs a lone wavefront 10-16 issue cycles, so the last group is as
+    // short as the list allows: GG = 3 reads 9 entries for the table scene's 9, GG = 4 would read 12).
+    // (the one-wavefront layout has no registers to spare for that: it reads and sums group by group)
+    constexpr int GG = 3, NGRP = (2 * NG + GG - 1) / GG;
+    constexpr bool BATCH = false;      // (measured on the two-wavefront layout: all reads up front 4.5 k cycles per product, group by group 4.1 k)
+    double t[NGRP * GG][3];
+    auto load_group = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-    for (int e0 = 0; e0 < 2 * NG; e0 += 4) {
-      if (e0 < n) {
-        double t[4][3];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int e = e0 + i;
+      for (int i = 0; i < GG; ++i) {
+        const int e = g * GG + i;
+        if (e < 2 * NG) {
           const unsigned row = (e & 1) ? (gat[e >> 1] >> 16) : (gat[e >> 1] & 0xffffu);
-          row3(sh_T, (int)row * NPT_RS, t[i]);
+          row3(sh_T, (int)row * NPT_RS, t[e]);
         }
+      }
+    };
+    if constexpr (BATCH) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int e = e0 + i;
-          if constexpr (NS == 1) {
+      for (int g = 0; g < NGRP; ++g)
+        if (g * GG < n) load_group(g);
+    }
 #pragma unroll
-            for (int q = 0; q < 3; ++q) acc[0][q] += t[i][q];
-          } else {
-            const double m0 = e < n0 ? 1.0 : 0.0, m1 = 1.0 - m0;     // (uniform)
+    for (int g = 0; g < NGRP; ++g) {
+      if (g * GG < n) {
+        if constexpr (!BATCH) load_group(g);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-              acc[0][q] = fma(m0, t[i][q], acc[0][q]);
-              acc[NS - 1][q] = fma(m1, t[i][q], acc[NS - 1][q]);
+        for (int i = 0; i < GG; ++i) {
+          const int e = g * GG + i;
+          if (e < 2 * NG) {
+            if constexpr (NS == 1) {
+#pragma unroll
+              for (int q = 0; q < 3; ++q) acc[0][q] += t[e][q];
+            } else {
+              const double m0 = e < n0 ? 1.0 : 0.0, m1 = 1.0 - m0;     // (uniform)
+#pragma unroll
+              for (int q = 0; q < 3; ++q) {
+                acc[0][q] = fma(m0, t[e][q], acc[0][q]);
+                acc[NS - 1][q] = fma(m1, t[e][q], acc[NS - 1][q]);
+              }
             }
           }
         }
@@ -711,6 +743,9 @@ struct NptCtx {
   // and the compiler keeps the LDS dependences (two wavefronts: the slot terms and their end nodes
   // all sit in wavefront 0 unless term_sync says otherwise).
   __device__ inline void ehess(const double (&W)[NE], double (&H)[NE]) {
+#ifdef GIK_NPT_PROF
+    long long pt = pf_now();
+#endif
 #pragma unroll
     for (int s = 0; s < NS; ++s)
       if (w_addr[s] >= 0) put3(sh_W, w_addr[s], &W[3 * s]);
@@ -783,12 +818,27 @@ struct NptCtx {
         put_term(u, t);
       }
     }
+    // The end nodes add the term vectors while the moment totals cross over to the other wavefront:
+    // the gather's LDS round trips hide behind the exchange (and its own behind the reduction network).
+    NPT_PF(0, pt)      // direction rows, moment contributions, term vectors
+    double tot_w = 0.0;
+    if (n_clq) {
+      tot_w = wave_sum24_distributed(v);
+      sum24_publish(tot_w);
+    }
+    NPT_PF(1, pt)      // reduction network
+    if constexpr (NW > 1) {
+      if (term_sync) __syncthreads();
+    }
+    gather_terms(acc);
+    NPT_PF(2, pt)      // gather
     if (n_clq) {
       // the 24 totals stay in ONE distributed register; its lanes are pre-scaled (diagonal of M + M^T
       // was reduced halved: x 2; T3: x -2; U3: x -1) and every total is fetched (v_readlane) where it is
       // used, by all of the lane's nodes at once -- groups fenced, so that no more than nine of them
       // occupy scalar registers at a time (all 24 up front overflow the SGPR file into spill lanes)
-      const double tot = sum24(v) * mscale;
+      const double tot = sum24_finish(tot_w) * mscale;
+      NPT_PF(3, pt)    // exchange with the other wavefront
       auto mo = [&](int q) { return readlane_f64(tot, npt_lane_of(q)); };
       double z[NS][3];
       {   // Sw: y~ . Sw, (r_i - |y~|^2) Sw_q, w_q cw
@@ -848,14 +898,15 @@ struct NptCtx {
 #pragma unroll
         for (int q = 0; q < 3; ++q) hq[s][q] = fma(2.0, z[s][q], hq[s][q]);
       if (dense_dw) clique_dw(W, acc);
-    } else if constexpr (NW > 1) {
-      if (term_sync) __syncthreads();      // (with a clique the barrier inside sum24 separates the term vectors from the gather)
     }
-    gather_terms(acc);
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int q = 0; q < 3; ++q) H[3 * s + q] = lm[s] * 2.0 * (acc[s][q] + hq[s][q]);
+    NPT_PF(4, pt)      // totals -> scalars, closed form
+#ifdef GIK_NPT_PROF
+    pf[9] += 1;
+#endif
   }
 
   // (D w)_i, dense: only for targets that are not distances of points (an arbitrary D_goal through

@@ -124,7 +124,8 @@ __device__ inline bool mig_anyone_waiting(const Ctx &cx, const MigCtl &m) {
   if (cx.lead()) {
     const unsigned int yt = __hip_atomic_load(m.y_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned int dn = __hip_atomic_load(m.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    w = yt + 4096u < m.y_cap && (unsigned)m.B > dn + (unsigned)m.waves;
+    // (every wave of the launch may be between this test and its push: the margin is the wave count)
+    w = yt + (unsigned)m.waves + 64u < m.y_cap && (unsigned)m.B > dn + (unsigned)m.waves;
   }
   return __builtin_amdgcn_readfirstlane(w) != 0;
 }

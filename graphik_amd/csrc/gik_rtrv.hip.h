@@ -147,7 +147,13 @@ __device__ inline void rtr_solve_vec(Ctx &cx, const Params &p, const gik_trace &
       auto step = [&](const double (&ec)[NE], const double (&hc)[NE], const double pc, double (&en)[NE],
                       double (&hn)[NE], double &pn) __attribute__((always_inline)) -> bool {
         double H[NE];
+#ifdef GIK_NPT_PROF
+        long long pt = cx.pf_now();
+#endif
         cx.ehess(delta, H);                      // :497
+#ifdef GIK_NPT_PROF
+        pt = cx.pf_now();
+#endif
         double v[8];
         cx.vert_dots(H, v[0], v[1], v[2]);
         v[3] = vdot(delta, H);
@@ -161,6 +167,9 @@ __device__ inline void rtr_solve_vec(Ctx &cx, const Params &p, const gik_trace &
         }
         v[7] = vdot(r, r);
         cx.template sum_n<8>(v);
+#ifdef GIK_NPT_PROF
+        { const long long t_ = cx.pf_now(); cx.pf[5] += t_ - pt; pt = t_; }      // inner products + reduction
+#endif
         double Hdelta[NE], uv[3];
         {
           const double rv[3] = {v[0], v[1], v[2]};
@@ -280,6 +289,9 @@ __device__ inline void rtr_solve_vec(Ctx &cx, const Params &p, const gik_trace &
         }
         e_Pd2 = beta * fma(alpha + alpha, d_Pd, e_Pd2);   // :596 (carried as 2 <eta, delta>)
         d_Pd = fma(beta * beta, d_Pd, new_r_r);           // :597
+#ifdef GIK_NPT_PROF
+        { const long long t_ = cx.pf_now(); cx.pf[6] += t_ - pt; }               // scalar step + vector updates
+#endif
         return false;
       };
       j = 0;
@@ -356,6 +368,10 @@ __device__ inline void rtr_solve_vec(Ctx &cx, const Params &p, const gik_trace &
     }
   }
   if (bad) stop = 2;
+#ifdef GIK_NPT_PROF
+  if (prof && lead)
+    for (int i = 0; i < 10; ++i) dbg_buf[16 + i] = (double)cx.pf[i];
+#endif
   if (prof && lead) {
     dbg_buf[0] = (double)prof_tcg;
     dbg_buf[1] = (double)inner_total;

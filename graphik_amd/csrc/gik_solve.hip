@@ -2344,7 +2344,7 @@ int gik_template_get_info(const gik_template *t, gik_template_info *info) {
   info->anchored = t->anchored ? 1 : 0;
   info->has_pipeline = t->has_pipe ? 1 : 0;
   info->prepare_is_block = t->prep_block ? 1 : 0;
-  info->node_per_lane = t->is_npt ? 1 : 0;
+  info->node_per_lane = t->is_npt ? t->npt_variant->NW : 0;
   if (t->is_npt) {
     info->waves_per_cu = t->npt_waves_per_cu;
     info->lds_bytes = (int32_t)t->npt_smem;

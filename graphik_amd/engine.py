@@ -153,8 +153,8 @@ class Template:
         _ffi.check(self.lib.gik_template_get_info(self._h, C.byref(info)))
         self.info = {f: getattr(info, f) for f, _ in _ffi.TemplateInfo._fields_ if f != "reserved"}
         deg = np.bincount(np.concatenate([self.term_i, self.term_j]), minlength=self.N).max()
-        sizes = (9, 10, 20) if (self.k == 3 and self.anchored) else ((9, 10) if self.k == 3 else (6, 16, 31))
-        self.maxdeg = next((m for m in sizes if m >= deg), int(deg))     # compiled slot count (or the raw degree: workgroup path)
+        # compiled slot count of the wavefront variant the library chose (or the raw degree: workgroup / node-per-lane paths)
+        self.maxdeg = int(self.info["max_terms_per_node"]) if not self.info["is_block"] else int(deg)
 
     @classmethod
     def from_matrices(cls, omega, psi_L=None, psi_U=None, k=3, use_limits=True, **kw):

@@ -27,6 +27,44 @@ _STOP_REASONS = {0: "Terminated - min grad norm reached", 1: "Terminated - max i
 BetaTypes = ["FletcherReeves", "PolakRibiere", "HestenesStiefel", "HagerZhang"]
 
 
+_closure_templates = {}
+
+
+def _cost_closures(D_goal, omega, psi_L, psi_U, use_limits):
+    """The closure triple of create_cost / create_cost_limits on the default device, reference
+    solver defaults; one cached Template per (k, masks)."""
+    omega = np.asarray(omega, dtype=float)
+    psi_L = None if psi_L is None else np.asarray(psi_L, dtype=float)
+    psi_U = None if psi_U is None else np.asarray(psi_U, dtype=float)
+    D_goal = np.asarray(D_goal, dtype=float)
+    state = {}
+
+    def tpl(Y):
+        k = int(np.asarray(Y).shape[-1])
+        if state.get("k") != k:
+            key = (k, use_limits, omega.tobytes(), None if psi_L is None else psi_L.tobytes(),
+                   None if psi_U is None else psi_U.tobytes())
+            if key not in _closure_templates:
+                _closure_templates[key] = Template.from_matrices(omega, psi_L, psi_U, k=k, use_limits=use_limits)
+            state["k"], state["T"] = k, _closure_templates[key]
+            state["tg"] = state["T"].targets_from_D(D_goal)
+        return state["T"], state["tg"]
+
+    def cost(Y):
+        T, tg = tpl(Y)
+        return float(T.cost(Y, tg)[0])
+
+    def egrad(Y):
+        T, tg = tpl(Y)
+        return T.grad(Y, tg)[0].cpu().numpy()
+
+    def ehess(Y, Z):
+        T, tg = tpl(Y)
+        return T.hess(Y, Z, tg)[0].cpu().numpy()
+
+    return cost, egrad, ehess
+
+
 class RiemannianSolver:
     def __init__(self, graph, params={}):
         self.params = params
@@ -75,28 +113,17 @@ class RiemannianSolver:
                 params=self.tr_params)
         return self._templates[key]
 
-    def create_cost(self, D_goal, omega, jit=True):
-        """(cost, egrad, ehess) closures like riemannian_solver.py:77-119, evaluated on the GPU."""
-        return self._closures(D_goal, omega, None, None, False)
+    @staticmethod
+    def create_cost(D_goal, omega, jit=True):
+        """(cost, egrad, ehess) closures like riemannian_solver.py:77-119 (a @staticmethod there too:
+        callable on the class), evaluated on the GPU.  The embedding dimension is taken from the
+        first point the closures see (Y.shape[1]); templates are cached per process."""
+        return _cost_closures(D_goal, omega, None, None, False)
 
-    def create_cost_limits(self, D_goal, omega, psi_L, psi_U, jit=True):
+    @staticmethod
+    def create_cost_limits(D_goal, omega, psi_L, psi_U, jit=True):
         """riemannian_solver.py:121-176"""
-        return self._closures(D_goal, omega, psi_L, psi_U, True)
-
-    def _closures(self, D_goal, omega, psi_L, psi_U, use_limits):
-        T = self._template(np.asarray(omega, dtype=float), psi_L, psi_U, use_limits)
-        tg = T.targets_from_D(D_goal)
-
-        def cost(Y):
-            return float(T.cost(Y, tg)[0])
-
-        def egrad(Y):
-            return T.grad(Y, tg)[0].cpu().numpy()
-
-        def ehess(Y, Z):
-            return T.hess(Y, Z, tg)[0].cpu().numpy()
-
-        return cost, egrad, ehess
+        return _cost_closures(D_goal, omega, psi_L, psi_U, True)
 
     # -- solve ----------------------------------------------------------------------------------
     def solve(self, D_goal, omega, use_limits=False, bounds=None, Y_init=None, jit=True,

@@ -18,6 +18,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests` on a machine without a GPU skips the gpu-marked tests instead of
+    erroring in their fixtures; an explicit `-m gpu` still fails loudly there (no silent pass)."""
+    if "gpu" in (config.getoption("-m") or ""):
+        return
+    try:
+        import torch
+        have = torch.cuda.is_available()
+    except Exception:
+        have = False
+    if have:
+        return
+    skip = pytest.mark.skip(reason="needs the MI355X (run with -m gpu on the GPU box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

@@ -237,7 +237,8 @@ def test_concurrent_batches_wave_path(torch_cuda):
     _serial_and_concurrent(torch, run, 16, 8)
 
 
-def test_concurrent_batches_block_path_with_time_slicing(torch_cuda, monkeypatch):
+@pytest.mark.parametrize("path", [1, 2])      # workgroup kernels / node-per-lane kernel
+def test_concurrent_batches_block_path_with_time_slicing(torch_cuda, monkeypatch, path):
     """Workgroup-per-problem kernels on one handle from 8 streams: the solve kernel with time slicing
     (more problems than resident workgroups: re-queue rings from the handle's pool of workspaces,
     shrunk to 4 here -- GIK_SLICE_POOL, read at create -- so that 24 launches in flight reuse every
@@ -248,10 +249,10 @@ def test_concurrent_batches_block_path_with_time_slicing(torch_cuda, monkeypatch
     robot, graph = make_graph("lwa4d")
     monkeypatch.setenv("GIK_SLICE_POOL", "4")
     prob = BatchProblem(graph, use_limits=True, force_block_prepare=True,
-                        params={"force_block_path": 1, "slice_outer_its": 24})
+                        params={"force_block_path": path, "slice_outer_its": 24})
     monkeypatch.delenv("GIK_SLICE_POOL")
     tpl = prob.template
-    assert tpl.info["is_block"] == 1
+    assert tpl.info["is_block"] == 1 and (tpl.info["node_per_lane"] != 0) == (path == 2)
     B = tpl.info["n_cu"] * tpl.info["waves_per_cu"] + 192        # more than fit at once -> slicing on
     Tgs = [torch.from_numpy(_goals(robot, B, 200 + i)).cuda() for i in range(12)]
 

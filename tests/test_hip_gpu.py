@@ -380,7 +380,7 @@ def test_full_size_batch_properties(torch_cuda):
     assert 0.6 < np.median(its[:48]) / np.median(o["iterations"]) < 1.6
 
 
-@pytest.mark.parametrize("name", ["lwa4d", "kuka", "lwa4d_block"])
+@pytest.mark.parametrize("name", ["lwa4d", "kuka", "lwa4d_block", "lwa4d_npt2", "lwa4d_npt1"])
 def test_checkpoint_resume_is_bit_identical(torch_cuda, monkeypatch, name):
     """After a rejected step the reference's next tCG solve repeats the previous one up to the
     smaller radius; the engine resumes from a checkpoint instead.  Same arithmetic, so the results
@@ -388,7 +388,9 @@ def test_checkpoint_resume_is_bit_identical(torch_cuda, monkeypatch, name):
     those of actually rerunning tCG (debug_flags = 16), bit for bit; only the executed work differs."""
     from graphik_amd.solvers.riemannian_solver import BatchProblem
     from graphik_amd.engine import Template
-    block = name.endswith("_block")          # the workgroup-per-problem kernel keeps its checkpoint too
+    block = "_" in name                      # the workgroup and node-per-lane kernels keep their checkpoint too
+    path = {"block": 1, "npt2": 2, "npt1": 2}.get(name.split("_")[-1], 0)     # gik_template_desc.force_block_path
+    npt_flags = 2048 if name.endswith("npt1") else 0                            # one wavefront per problem
     robot, graph = make_graph(name.split("_")[0])
     prob = BatchProblem(graph, use_limits=True)
     rng = np.random.RandomState(21)
@@ -396,7 +398,7 @@ def test_checkpoint_resume_is_bit_identical(torch_cuda, monkeypatch, name):
     targets, Y0 = prob.prepare(Tg)
     def template(debug_flags):
         return Template.from_matrices(prob.omega, prob.psi_L, prob.psi_U, k=3, use_limits=True,
-                                      params={"force_block_path": int(block), "debug_flags": debug_flags})
+                                      params={"force_block_path": path, "debug_flags": debug_flags | npt_flags})
 
     def run(debug_flags=0):
         r = template(debug_flags).solve(Y0, targets, trace_cap=96)
@@ -415,8 +417,10 @@ def test_checkpoint_resume_is_bit_identical(torch_cuda, monkeypatch, name):
     assert a["inner_executed"].sum() < 0.95 * b["inner_executed"].sum()   # measured: -11 ... -14 %
 
 
-@pytest.mark.parametrize("flags", [0, 64])     # 64: with the clique closed form (base + goal nodes)
-def test_time_slicing_is_bit_identical(torch_cuda, monkeypatch, flags):
+@pytest.mark.parametrize("path,flags", [(1, 0), (1, 64), (2, 0), (2, 64), (2, 64 | 2048)])
+#                          path 1: workgroup kernel, 2: node-per-lane kernel (2048: one wavefront per problem);
+#                          64: with the clique closed form (base + goal nodes)
+def test_time_slicing_is_bit_identical(torch_cuda, monkeypatch, path, flags):
     """The workgroup-per-problem kernel re-queues a problem that has not met a stopping rule after
     slice_outer_its outer iterations (default 96) behind everything that is waiting, so that the long
     problems of a batch do not start last.  A solve is exactly resumable from (x, Delta,
@@ -433,8 +437,9 @@ def test_time_slicing_is_bit_identical(torch_cuda, monkeypatch, flags):
     runs = {}
     for sl in ("0", "256", "24"):
         tpl = Template.from_matrices(prob.omega, prob.psi_L, prob.psi_U, k=3, use_limits=True,
-                                     params={"force_block_path": 1, "slice_outer_its": int(sl),
+                                     params={"force_block_path": path, "slice_outer_its": int(sl),
                                              "debug_flags": flags})
+        assert (tpl.info["node_per_lane"] != 0) == (path == 2)
         r = tpl.solve(Y0, targets, trace_cap=40)
         runs[sl] = {k: r[k].cpu().numpy() for k in keys + ("inner_executed",)}
         runs[sl]["numit"] = r["trace"]["numit"].cpu().numpy()
@@ -523,6 +528,11 @@ def test_drop_in_single_goal(torch_cuda):
     cost, egrad, ehess = solver.create_cost(dgp.distance_matrix_from_graph(G),
                                             dgp.adjacency_matrix_from_graph(G))
     assert cost(info["x"]) < 1e-20 and egrad(info["x"]).shape == (13, 2)
+    # ... and on the class, as the reference's static methods are called (riemannian_solver.py:77-78)
+    c2, g2, h2 = RiemannianSolver.create_cost(dgp.distance_matrix_from_graph(G), dgp.adjacency_matrix_from_graph(G))
+    assert c2(info["x"]) == cost(info["x"]) and np.array_equal(g2(info["x"]), egrad(info["x"]))
+    W = np.random.RandomState(0).randn(13, 2)
+    assert np.array_equal(h2(info["x"], W), ehess(info["x"], W))
 
 
 # ---- device pre/post-processing (gik_prepare_batch / gik_recover_batch / gik_ik_batch) ----------
@@ -772,9 +782,10 @@ def test_device_pipeline_end_to_end(torch_cuda, name, B):
 # debug_flags of the workgroup-per-problem path: 64 = closed form for rigid cliques from 4 nodes up
 # (default 16: the small robots' base + goal nodes then exercise it), 128 = closed form off,
 # 256 = closed form with the dense D w product even when the targets are distances of points
+@pytest.mark.parametrize("path", [1, 2])      # gik_template_desc.force_block_path: workgroup kernels / node-per-lane kernel
 @pytest.mark.parametrize("name,flags", [("ur10_table", 0), ("ur10_table", 256), ("ur10_table", 128), ("lwa4d", 0), ("lwa4d", 64),
-                                        ("kuka", 64), ("planar10_limits_halfpi", 0)])
-def test_block_path_known_answers(torch_cuda, name, flags):
+                                        ("kuka", 64), ("planar10_limits_halfpi", 0), ("ur10_table", 2048), ("ur10", 64 | 2048)])
+def test_block_path_known_answers(torch_cuda, name, flags, path):
     """UR10 + table_environment(): 116 nodes, 5612 residual terms (BASELINE configs[2]) runs on
     the workgroup-per-problem kernels; the small graphs are forced onto the same kernels so both
     code paths are checked against the same golden vectors.  The table scene's 106 anchors form a
@@ -783,8 +794,13 @@ def test_block_path_known_answers(torch_cuda, name, flags):
     from graphik_amd.engine import Template
     d = load_golden(name)
     use_lim = bool(int(d["use_limits"]))
+    if path == 2 and (int(d["dim"]) == 2 or (name == "ur10_table" and flags == 128)):
+        pytest.skip("node-per-lane kernel: 3-D graphs with at most 256 terms outside a rigid clique")
+    if path == 1 and flags & 2048:
+        pytest.skip("2048 selects the one-wavefront layout of the node-per-lane kernel")
     T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=int(d["dim"]),
-                               use_limits=use_lim, params={"force_block_path": 1, "debug_flags": flags})
+                               use_limits=use_lim, params={"force_block_path": path, "debug_flags": flags})
+    assert T.info["is_block"] == 1 and T.info["node_per_lane"] == (0 if path == 1 else (1 if flags & 2048 else 2))
     key = "lim" if use_lim else "nolim"
     tg = T.targets_from_D(d["D_goal"][0])
     Y, W = d["kat_Y"], d["kat_W"]
@@ -794,8 +810,10 @@ def test_block_path_known_answers(torch_cuda, name, flags):
     assert rel_err(T.proj(Y, W).cpu().numpy(), d["kat_proj"]) < 1e-12
 
 
-@pytest.mark.parametrize("name,flags", [("lwa4d", 0), ("lwa4d", 64), ("ur10", 64), ("planar10_limits_halfpi", 0)])
-def test_block_path_trajectories_match_wave_path(torch_cuda, name, flags):
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("name,flags", [("lwa4d", 0), ("lwa4d", 64), ("ur10", 64), ("planar10_limits_halfpi", 0),
+                                        ("lwa4d", 64 | 2048)])
+def test_block_path_trajectories_match_wave_path(torch_cuda, name, flags, path):
     """The two kernel paths sum the same terms in different orders, so on 3-D goals they part where
     round-off is amplified to 1e-8 -- like any two renderings of the algorithm (stable_prefix).  Strict:
     decisions identical and f to 1e-7 for 5 (3-D) / 8 (planar) outer iterations on every goal; and the
@@ -804,10 +822,12 @@ def test_block_path_trajectories_match_wave_path(torch_cuda, name, flags):
     from graphik_amd.engine import Template
     d = load_golden(name)
     use_lim = bool(int(d["use_limits"]))
+    if (path == 2 and int(d["dim"]) == 2) or (path == 1 and flags & 2048):
+        pytest.skip("node-per-lane kernel: 3-D graphs; 2048 is its one-wavefront layout")
     kw = dict(k=int(d["dim"]), use_limits=use_lim)
     Tw = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], **kw)
     Tb = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"],
-                                params={"force_block_path": 1, "debug_flags": flags}, **kw)
+                                params={"force_block_path": path, "debug_flags": flags}, **kw)
     tg = Tw.targets_from_D(d["D_goal"])
     from parity_util import first_divergence, report
     rw = Tw.solve(d["Y_init"], tg, trace_cap=32)
@@ -824,7 +844,7 @@ def test_block_path_trajectories_match_wave_path(torch_cuda, name, flags):
     iw, ib = rw["iterations"].cpu().numpy(), rb["iterations"].cpu().numpy()
     n = [min(32, int(iw[g]), int(ib[g])) for g in range(len(iw))]      # (planar solves end after 7-13 iterations)
     part = [first_divergence({k: tw[k][g] for k in tw}, {k: tb[k][g] for k in tb}, n[g]) for g in range(len(iw))]
-    report(f"trajectory_prefix/{name}/block_vs_wave/flags{flags}", {"paths_part_at": part, "compared": n})
+    report(f"trajectory_prefix/{name}/{'block' if path == 1 else 'npt'}_vs_wave/flags{flags}", {"paths_part_at": part, "compared": n})
     if int(d["dim"]) == 3:      # (planar solves reach f ~ 1e-28 within 8-14 iterations: relative 1e-8 on f and
         #                         |grad| loses its meaning there; the strict check above is the planar bar)
         assert all(p >= min(m, q) for p, q in zip(part, n)), (part, n)
@@ -912,9 +932,17 @@ def test_clique_detection_on_synthetic_graphs(torch_cuda, n_clique, n_other, euc
     want = (co.lcost(Y, D, om, pL, pU, il), co.lgrad(Y, D, om, pL, pU, il), co.lhess(Y, W, D, om, pL, pU, il))
     fs = []
     # (the largest case only fits the LDS with the clique taken out of the slot tables)
-    for flags in ((0, 256, 128) if n_clique < 64 else (0, 256)):
-        T = Template.from_matrices(om, pL, pU, k=3, use_limits=True,
-                                   params={"force_block_path": 1, "debug_flags": flags})
+    # both kernel families: (force_block_path, debug_flags); the node-per-lane kernel needs the clique
+    # taken out (at most 256 terms outside it, at most 16 per node), in both of its layouts
+    cases = [(1, f) for f in ((0, 256, 128) if n_clique < 64 else (0, 256))] + [(2, 0), (2, 256), (2, 2048)]
+    for path, flags in cases:
+        try:
+            T = Template.from_matrices(om, pL, pU, k=3, use_limits=True,
+                                       params={"force_block_path": path, "debug_flags": flags})
+        except RuntimeError as e:
+            assert path == 2 and "node-per-lane" in str(e), e      # a node with more than 16 terms outside the clique
+            continue
+        assert (T.info["node_per_lane"] != 0) == (path == 2)
         tg = T.targets_from_D(D)
         assert rel_err(float(T.cost(Y, tg)[0]), want[0]) < 1e-12
         assert rel_err(T.grad(Y, tg)[0].cpu().numpy(), want[1]) < 1e-12
@@ -922,7 +950,7 @@ def test_clique_detection_on_synthetic_graphs(torch_cuda, n_clique, n_other, euc
         r = T.solve(Y[None], tg[None] if tg.ndim == 1 else tg)
         fs.append(float(r["f"][0]))
         # which rendering of the clique's D w product ran (gik_stats.flags bit 0)
-        assert int(r["flags"][0]) == (1 if (euclid is True and flags == 0) else 0)
+        assert int(r["flags"][0]) == (1 if (euclid is True and not flags & (128 | 256)) else 0)
     if euclid is True:
         assert max(fs) < 1e-9
     else:                       # inconsistent targets / hinges: a positive minimum, the same for both renderings
@@ -966,8 +994,10 @@ def test_busy_nodes_fall_back_to_block_path(torch_cuda):
     assert float(r["f"][0]) < 1e-9 and int(r["stop"][0]) == 0
 
 
-def test_ur10_table_solve(torch_cuda):
-    """BASELINE configs[2] on the workgroup-per-problem kernel: the 8 captured goals from the
+@pytest.mark.parametrize("path", [0, 1])      # 0: automatic = the node-per-lane kernel; 1: the workgroup kernel
+def test_ur10_table_solve(torch_cuda, path):
+    """BASELINE configs[2] on the node-per-lane kernel (the default for this graph) and on the
+    workgroup-per-problem kernel: the 8 captured goals from the
     reference's own Y_init.  Per goal: trajectory prefix against the oracle at the contract's
     tolerance (as far as the reference's numpy path and the oracle are the same computation, see
     test_trajectory_prefix_3d), the reference's convergence class (one of the goals ends in a local
@@ -980,7 +1010,8 @@ def test_ur10_table_solve(torch_cuda):
     robot, graph = make_graph("ur10_table")
     G = len(d["seed"])
     assert G >= 8
-    T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=3, use_limits=True)
+    T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=3, use_limits=True, params={"force_block_path": path})
+    assert T.info["is_block"] == 1 and T.info["node_per_lane"] == (2 if path == 0 else 0)
     tg = T.targets_from_D(d["D_goal"])
     r = T.solve(np.concatenate([d["Y_init"], d["Y_init"]]), np.concatenate([tg, tg]), trace_cap=48)
     x = r["x"].cpu().numpy()
@@ -1004,7 +1035,7 @@ def test_ur10_table_solve(torch_cuda):
             q = graph.joint_variables(x[g], d["T_goal"][g])
             T_sol = robot.pose(q, "p6")
             assert np.linalg.norm(T_sol.trans - d["T_goal"][g][:3, 3]) < 3 * d["pos_err"][g] + 1e-4
-    report("trajectory_prefix/ur10_table/block", {"strictly_pinned_iterations": pinned,
+    report("trajectory_prefix/ur10_table/" + ("npt" if path == 0 else "block"), {"strictly_pinned_iterations": pinned,
            "hip_leaves_oracle_at": k_hip, "reference_np_leaves_oracle_at": k_ref,
            "iterations_hip": its.tolist(), "iterations_reference": d["iterations"].tolist()})
     assert np.mean(np.array(k_hip) >= np.array(k_ref)) >= 2.0 / 3.0

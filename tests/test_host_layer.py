@@ -146,6 +146,17 @@ def test_api_surface():
     assert np.allclose(robot.q_to_array(q), -np.pi + 2 * np.pi * u)  # robot_base.py:76-85
     with pytest.raises(Exception):
         rs.RiemannianSolver(graph, {"solver": "nope"})
+    # static in the reference (riemannian_solver.py:67-78, 121-122): callable on the class, no instance
+    for name, params in (("create_cost", ["D_goal", "omega", "jit"]),
+                         ("create_cost_limits", ["D_goal", "omega", "psi_L", "psi_U", "jit"]),
+                         ("generate_initialization", None)):
+        assert isinstance(inspect.getattr_static(rs.RiemannianSolver, name), staticmethod), name
+        if params:
+            assert list(inspect.signature(getattr(rs.RiemannianSolver, name)).parameters) == params
+    om = np.ones((4, 4)) - np.eye(4)
+    triple = rs.RiemannianSolver.create_cost(np.zeros((4, 4)), om)      # closures only: nothing touches a GPU yet
+    assert len(triple) == 3 and all(callable(f) for f in triple)
+    assert len(rs.RiemannianSolver.create_cost_limits(np.zeros((4, 4)), om, 0 * om, 0 * om)) == 3
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/graphik/robots/urdfs"),
