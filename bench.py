@@ -59,6 +59,13 @@ def algorithmic_flops(N, k, T, n_inner, n_outer, n_accept):
     return n_inner * F_hv + n_outer * F_cost + n_accept * F_acc
 
 
+def prepare_flops(N, K):
+    """F_init ~ 2 * 9 N^3 + 9 K^3 (two N x N and one K x K Jacobi-class eigendecomposition) per
+    goal, plus bound smoothing as the kernels run it: Floyd-Warshall on UPPER (N^3 add + min = 2 N^3) and
+    the two-stage max-plus pass for LOWER (2 N^3).  K: the MDS column count the kernel reports per goal."""
+    return 2 * 9 * N ** 3 + 9 * np.asarray(K, dtype=float) ** 3 + 4 * N ** 3
+
+
 def algorithmic_bytes(N, k, T):
     """HBM bytes the solve kernel must move per IK problem: T targets + Y_init in, Y_sol + stats
     out (SURVEY 8(d) counts the pipeline-level 616 B/solve; the dominant kernel alone sees this)."""
@@ -150,15 +157,17 @@ def workload(args, world):
     return cfg, robot_name, total, ("weak" if mode == "per_gpu" else "strong")
 
 
-def dry_results(T_goal):
-    """Deterministic per-goal stand-in for [pos_err, rot_err, iterations, inner_total, n_accept,
-    stop, inner_executed] (--dry-solve): a function of the goal pose alone, so the gathered table
-    must equal the single-process one row for row."""
+def dry_solve(T_goal, n):
+    """Deterministic per-goal stand-in for the device solve (--dry-solve): q and every statistic of
+    graphik_amd.distributed.RESULT_STATS as a function of the goal pose alone, so the table gathered
+    from N ranks must equal the single-process one row for row."""
     flat = T_goal.reshape(len(T_goal), -1)
     key = np.abs(flat).sum(axis=1)
     its = 1.0 + np.floor(997.0 * (key - np.floor(key)))
-    return np.stack([1e-4 * key, 1e-4 * (key + 1.0), its, 40.0 * its, np.floor(0.8 * its),
-                     np.zeros_like(key), 38.0 * its], axis=1)
+    q = np.sin(key[:, None] * (1.0 + np.arange(n)[None, :]))
+    return {"q": q, "pos_err": 1e-4 * key, "rot_err": 1e-4 * (key + 1.0), "f": 1e-12 * key, "gradnorm": 1e-10 * key,
+            "iterations": its, "inner_total": 40.0 * its, "n_accept": np.floor(0.8 * its),
+            "stop": np.zeros_like(key), "inner_executed": 38.0 * its}
 
 
 def cpu_baseline(prob, T_goal, Y0_h, B, args):
@@ -185,9 +194,11 @@ def cpu_baseline(prob, T_goal, Y0_h, B, args):
         return dt, int(o["inner_total"].sum())
 
     big = prob.N * prob.dim > 64            # table scene: ~1 s per solve per thread
-    n1 = min(B, 2 if big else 24)
+    planar = prob.dim == 2                  # ~50 products per solve
+    n1 = min(B, 2 if big else (256 if planar else 24))
     t1, hv1 = run(n1, 1)
-    ns = args.cpu_sample or min(B, 2 * cores if big else max(64, 64 * cores))   # ~15 s of CPU work
+    # a bounded sample (>= 256 problems per config, the table scene >= 16): ~5-20 s of CPU work
+    ns = args.cpu_sample or min(B, max(16, 2 * cores) if big else (4096 if planar else max(256, 64 * cores)))
     tc, hvc = run(ns, cores)
     return {
         "value": ns / tc, "unit": "solves/s", "cores": cores, "kind": "port",
@@ -265,14 +276,15 @@ class Bench:
         robot, graph = build_graph(robot_name)
         T_goal, B = self.goals(robot, total, self.args.seed)
         for _ in range(warmup):
-            st = dry_results(T_goal)
+            st = dry_solve(T_goal, robot.n)
         gd.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            st = dry_results(T_goal)
+            st = dry_solve(T_goal, robot.n)
         gd.barrier()
         dt = gd.max_over_ranks(time.perf_counter() - t0, self.dev)
-        allstats = gd.gather_rows(torch.from_numpy(st), total, dst=0)
+        # the library's result table (q + statistics per problem) and its ONE gather
+        allstats = gd.gather_rows(gd.pack_results(st), total, dst=0)
         if self.rank != 0:
             return None
         a = allstats.numpy()
@@ -282,17 +294,18 @@ class Bench:
             "ms_per_step": dt / steps * 1e3, "scaling": scaling,
             "config": {"workload": f"{robot_name}, {total} goals over {self.world} rank(s)",
                        "config": cfg, "robot": robot_name, "goals_total": total},
-            "rows": int(a.shape[0]), "checksum": float(a.sum()),
+            "rows": int(a.shape[0]), "row_bytes": int(a.shape[1]) * 8, "checksum": float(a.sum()),
             "rows_sha": __import__("hashlib").sha256(np.ascontiguousarray(a).tobytes()).hexdigest(),
         }
 
     def measure(self, cfg, robot_name, total, scaling, steps, warmup, serving_streams=0,
-                cpu=False, n_streams=1, intended=False):
+                cpu=False, n_streams=1, intended=False, seed=None):
         if self.dry:
             return self.measure_dry(cfg, robot_name, total, scaling, steps, warmup)
         args, torch, gd, dev, rank, world = self.args, self.torch, self.gd, self.dev, self.rank, self.world
+        seed = args.seed if seed is None else seed
         robot, graph = build_graph(robot_name)
-        T_goal, B = self.goals(robot, total, args.seed)
+        T_goal, B = self.goals(robot, total, seed)
         from graphik_amd.solvers.riemannian_solver import AnchoredProblem, BatchProblem
         anch = None
         if intended:
@@ -314,6 +327,8 @@ class Bench:
         torch.cuda.synchronize(dev)
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        evp = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]     # before the prepare kernel
+        evr = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]     # after the recover kernel
 
         anch_ms = []
 
@@ -326,16 +341,24 @@ class Bench:
                     anch_ms.append(anch.template)
                 res.update(Y0=res["x"])
                 return res
-            targets, Y0 = tpl.prepare(Tg_dev) if on_device else (tg_dev, Y0_dev)
             if i is not None:
-                ev0[i].record()      # all kernels are launched on torch's current stream
+                evp[i].record()      # all kernels are launched on torch's current stream
+            Kc = None
+            if on_device:
+                targets, Y0, Kc = tpl.prepare(Tg_dev, return_K=True)
+            else:
+                targets, Y0 = tg_dev, Y0_dev
+            if i is not None:
+                ev0[i].record()
             res = tpl.solve(Y0, targets)
             if i is not None:
                 ev1[i].record()
             if on_device:
                 q, pe, re = tpl.recover(res["x"], Tg_dev)
                 res.update(q=q, pos_err=pe, rot_err=re)
-            res.update(Y0=Y0)
+            if i is not None:
+                evr[i].record()
+            res.update(Y0=Y0, K=Kc)
             return res
 
         for _ in range(warmup):
@@ -367,6 +390,10 @@ class Bench:
         else:
             ks = [float(a.elapsed_time(b)) for a, b in zip(ev0, ev1)]
             kernel_ms = float(np.mean(ks))
+        prep_ms = recover_ms = None
+        if anch is None and on_device:
+            prep_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(evp, ev0)]))
+            recover_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev1, evr)]))
 
         # Serving configuration, reported separately (NOT `value`): the same batches, S in flight on
         # separate HIP streams, so the straggler tail of one batch overlaps with the bulk of the next.
@@ -396,13 +423,12 @@ class Bench:
         if not on_device:   # host post-processing, after the timed region
             qh = prob.joint_variables(res["x"].cpu().numpy(), T_goal)
             pe, re = prob.pose_errors(qh, T_goal)
-            res.update(pos_err=torch.from_numpy(pe).to(dev), rot_err=torch.from_numpy(re).to(dev))
+            res.update(pos_err=torch.from_numpy(pe).to(dev), rot_err=torch.from_numpy(re).to(dev),
+                       q=torch.from_numpy(np.asarray(qh, dtype=float)).to(dev))
 
-        # single gather of the per-problem results at the end (RCCL over xGMI when N > 1)
-        stats_local = torch.stack([res["pos_err"], res["rot_err"], res["iterations"].double(),
-                                   res["inner_total"].double(), res["n_accept"].double(),
-                                   res["stop"].double(), res["inner_executed"].double()], dim=1)
-        allstats = gd.gather_rows(stats_local, total, dst=0)
+        # single gather of the per-problem results at the end (RCCL over xGMI when N > 1): the table of
+        # graphik_amd.distributed.solve_batch_sharded -- joint angles + statistics per problem
+        allstats = gd.gather_rows(gd.pack_results(res, device=dev), total, dst=0)
         Y0_h = res["Y0"].cpu().numpy()
 
         flags_local = res["flags"] if "flags" in res else None
@@ -412,11 +438,16 @@ class Bench:
         st = allstats.cpu().numpy()
         import hashlib
         import torch.distributed as dist
-        gather = {"rows": int(st.shape[0]), "backend": dist.get_backend() if dist.is_initialized() else None,
+        gather = {"rows": int(st.shape[0]), "bytes_per_problem": int(st.shape[1]) * 8,
+                  "bytes": int(st.shape[0]) * int(st.shape[1]) * 8,
+                  "backend": dist.get_backend() if dist.is_initialized() else None,
                   "sha256": hashlib.sha256(np.ascontiguousarray(st).tobytes()).hexdigest(),
-                  "note": "per-problem results [pos_err, rot_err, iterations, hv, accepted, stop, hv executed] "
-                          "of all ranks on rank 0: the ONE collective of the job (all_gather over RCCL)"}
-        pos, rot, its, inner, nacc, stop, execd = st.T
+                  "note": "per-problem results of all ranks on rank 0, the ONE collective of the job (all_gather over "
+                          "RCCL): q [n] + " + ", ".join(gd.RESULT_STATS) + " -- the table of "
+                          "graphik_amd.distributed.solve_batch_sharded (the points Y travel on request: with_Y)"}
+        _, _, ginfo = gd.unpack_results(st, robot.n)
+        pos, rot, its, inner, nacc, stop, execd = (ginfo[k].astype(float) for k in (
+            "pos_err", "rot_err", "iterations", "inner_total", "n_accept", "stop", "inner_executed"))
         inner_local = float(res["inner_total"].double().sum())        # as the reference counts them
         exec_local = float(res["inner_executed"].double().sum())      # Hessian products evaluated
         outer_local = float(res["iterations"].double().sum())
@@ -447,7 +478,7 @@ class Bench:
                                    (f"BASELINE configs[{base_idx}]" if base_idx is not None else "parity config")
                                    + "), reference solver defaults (mingradnorm 5e-10, maxiter 3000)",
                        "config": cfg, "robot": robot_name, "goals_total": total, "batch_per_gpu": B,
-                       "seed": args.seed,
+                       "seed": seed,
                        "step": ("goal poses (HBM) -> prepare kernel (goal distances, bound smoothing, "
                                 "MDS init) -> RTR solve kernel -> recover kernel (joint angles, FK "
                                 "pose error); no host work inside the timed region") if on_device else
@@ -491,6 +522,25 @@ class Bench:
         out["gather"] = gather
         if serving is not None:
             out["serving"] = serving
+        # every kernel of the step (HIP events on the launch stream), which of them dominates, and -- when it
+        # is the prepare kernel (planar-10: c5) -- its own roofline entry next to the solve kernel's
+        if prep_ms is not None:
+            K_local = res["K"].double().cpu().numpy()
+            pf = float(prepare_flops(N, K_local).sum())
+            prep_name = "prep_block_kernel" if info and info.get("prepare_is_block") else "prep_wave_kernel"
+            out["kernels"] = {"prepare_ms": prep_ms, "solve_ms": kernel_ms, "recover_ms": recover_ms,
+                              "dominant": prep_name if prep_ms > kernel_ms else kernel_name}
+            out["roofline_prepare"] = {
+                "bound": "fp64-valu", "kernel": prep_name, "kernel_ms": prep_ms,
+                "achieved": pf / (prep_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": pf / (prep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "flops_per_launch": pf,
+                "mds_columns_median": float(np.median(K_local)),
+                "note": "goal distances + bound smoothing + MDS initial point, one wavefront (workgroup) per goal; "
+                        "SURVEY 8(d): F_init = 2 * 9 N^3 + 9 K^3 per goal with the K the kernel reports, + 4 N^3 for "
+                        "Floyd-Warshall (UPPER) and the max-plus pass (LOWER); LDS resident, bound by instruction "
+                        "issue of the cyclic Jacobi sweeps (DESIGN 4.3)"}
+        else:
+            out["kernels"] = {"prepare_ms": None, "solve_ms": kernel_ms, "recover_ms": None, "dominant": out["roofline"]["kernel"]}
         # HBM traffic of the solve kernel from the PMC passes of the SAME workload (tools/profile.sh:
         # rocprofv3 cannot run inside this process), newest round first; null for unprofiled workloads
         tags = {("lwa4d", 4096): ["r04", "r03", "r02"], ("ur10_table", 4096): ["r04_c3"],
@@ -545,7 +595,11 @@ def brief(o):
             "success_rate": o["success_rate"], "frac_maxiter": o["frac_maxiter"],
             "median_pos_err_m": o["median_pos_err_m"], "median_rot_err_rad": o["median_rot_err_rad"],
             "outer_iterations": o["outer_iterations"],
-            "hv_products_executed_per_gpu": o["hv_products"]["executed_per_gpu"]}
+            "hv_products_executed_per_gpu": o["hv_products"]["executed_per_gpu"],
+            "kernels": o.get("kernels"), "roofline_prepare": o.get("roofline_prepare"),
+            "cpu_baseline": ({k: o["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample",
+                                                                 "hv_per_s_per_thread")}
+                             if "cpu_baseline" in o else None)}
 
 
 def main():
@@ -574,11 +628,21 @@ def main():
         if b.world == 1:
             plan.insert(2, ("c4_share_of_8", "kuka", 8192, "strong", 5, 1))
         for name, rb, tot, sc, st, wu in plan:
-            o = b.measure(name[:2], rb, tot, sc, st, wu)
+            o = b.measure(name[:2], rb, tot, sc, st, wu, cpu=(name != "c4_share_of_8"))
             if b.rank == 0:
                 extra[name] = brief(o)
+        # the headline on seeds 0-3: `value` stays seed 0; a 4096-goal batch is as long as
+        # the longest problem of its draw
+        per_seed = [out["ms_per_step"] if b.rank == 0 else None]
+        for sd in (1, 2, 3):
+            o = b.measure(cfg, robot_name, total, scaling, 3, 1, seed=sd)
+            per_seed.append(o["ms_per_step"] if b.rank == 0 else None)
         if b.rank == 0:
             out["configs"] = extra
+            out["seeds"] = {"seeds": [0, 1, 2, 3], "ms_per_step": per_seed, "median_ms_per_step": float(np.median(per_seed)),
+                            "value_at_median": total / (float(np.median(per_seed)) * 1e-3),
+                            "note": "same workload, goal streams of seeds 0-3 (seed 0 = `value`, steps as given; seeds 1-3: "
+                                    "3 steps after 1 warm-up)"}
     b.gd.shutdown()
     if b.rank == 0:
         print(json.dumps(out), flush=True)

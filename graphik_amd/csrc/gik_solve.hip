@@ -1148,6 +1148,7 @@ struct gik_template {
   int dbg;            // SolveArgs::dbg
   int wpc_override;   // persistent waves per CU, 0 = automatic
   int slice_its;      // time slice of the block kernel in outer iterations, 0 = off
+  int npt_slice_its = 128;   // ... of the node-per-lane kernel
   int wave_slice_its; // round-robin slice of the wavefront kernel (large batches), 0 = off
   int wave_slice_cycles = 2000000;   // ... and its shortest duration (GIK_SLICE_CYCLES)
   int waves_per_cu;  // resident solve wavefronts per CU (from the occupancy query)
@@ -1633,12 +1634,15 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   // 755 / 586 / 368 MB of HBM traffic per launch (every resumed slice re-reads the problem's 45 KB of
   // targets; 207 MB are the algorithmic bytes).  Without slicing: ~15 % slower (round 2: 795 vs 929).
   t->slice_its = d->slice_outer_its < 0 ? 256 : d->slice_outer_its;
+  // node-per-lane kernel, table scene, 4096 goals (round 4): slice 0 / 48 / 96 / 256 / 600 -> 1689 / 1896 / 1894 / 1861 /
+  // 1774 solves/s (two problems per CU: 512 slots, a third of the requeues of the workgroup kernel)
+  t->npt_slice_its = d->slice_outer_its < 0 ? 128 : d->slice_outer_its;
   // developer overrides, read once here (never inside a batch call)
   if (const char *e = getenv("GIK_WAVES_PER_CU")) t->wpc_override = std::max(1, atoi(e));
   // wavefront kernel: 256 ... 32 iterations per slice give the same time (NOTEBOOK 8.3); the longest of
   // them moves the fewest problems through HBM (KUKA 65536: 118 k hand-overs of ~1.5 KB instead of 562 k at 64)
   t->wave_slice_its = d->slice_outer_its < 0 ? 256 : d->slice_outer_its;
-  if (const char *e = getenv("GIK_SLICE")) t->slice_its = t->wave_slice_its = std::max(0, atoi(e));
+  if (const char *e = getenv("GIK_SLICE")) t->slice_its = t->npt_slice_its = t->wave_slice_its = std::max(0, atoi(e));
   if (const char *e = getenv("GIK_SLICE_CYCLES")) t->wave_slice_cycles = std::max(0, atoi(e));
   t->d_slot_meta = nullptr;
   t->d_counters = nullptr;
@@ -2240,7 +2244,7 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   // Time slicing (workgroup-per-problem kernel): only when there are more problems than resident
   // workgroups (otherwise everything starts at once anyway).  Slice length: the handle's
   // slice_outer_its, 0 disables.  Measured on UR10 + table, 4096 goals: 8.9 -> 7.7 s.
-  int slice = t->slice_its;
+  int slice = t->is_npt ? t->npt_slice_its : t->slice_its;
   const bool cg = t->solver == GIK_SOLVER_CONJUGATE_GRADIENT;
   if (!t->is_block || cg || B <= grid || (a.dbg & 1) || slice <= 0 || t->p.maxiter <= slice) slice = 0;
   a.slice_its = slice;

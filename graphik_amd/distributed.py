@@ -1,8 +1,17 @@
 """Multi-GPU sharding of an IK batch: one process per GPU, contiguous shards, no data-path
-collective; one gather of the results at the end (torch.distributed: RCCL over xGMI on the GPU
-box, gloo on CPU for tests).  IK goals are independent, so nothing else is exchanged."""
+collective; ONE gather of the results at the end (torch.distributed: RCCL over xGMI on the GPU
+box, gloo on CPU for tests).  IK goals are independent, so nothing else is exchanged.
+
+    q, Y, info = solve_batch_sharded(graph, T_goals)        # every rank calls it with the full batch
+
+is the multi-GPU twin of solvers.riemannian_solver.solve_batch (what ONE rank returns is what
+solve_with_riemannian returns per goal, graphik/solvers/riemannian_solver.py:220-234: the joint
+angles and the point matrix): rank r solves rows shard_range(B, r, world) on its GPU and the
+per-problem results -- q [n], the statistics, on request the points Y [N*k] (~520 B
+per problem at N = 18) -- are gathered on rank `dst` in one collective."""
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -54,6 +63,80 @@ def gather_rows(local, total, dst=0):
     if rank != dst:
         return None
     return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+# the per-problem statistics that travel with q (one float64 column each, in this order)
+RESULT_STATS = ("pos_err", "rot_err", "f", "gradnorm", "iterations", "inner_total", "n_accept", "stop",
+                "inner_executed")
+
+
+def pack_results(res, with_Y=False, device=None):
+    """One float64 row per problem of this rank's shard: q [n] | RESULT_STATS | (Y [N*k]).
+    `res`: dict of tensors or arrays with keys "q", RESULT_STATS and (with_Y) "x"."""
+    def col(v):
+        t = v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))
+        t = t.to(torch.float64)
+        if device is not None:
+            t = t.to(device)
+        return t.reshape(t.shape[0], -1)
+    cols = [col(res["q"])] + [col(res[k]) for k in RESULT_STATS]
+    if with_Y:
+        cols.append(col(res["x"]))
+    return torch.cat(cols, dim=1).contiguous()
+
+
+def unpack_results(table, n, with_Y=False, point_shape=None):
+    """Inverse of pack_results on the gathered [B, width] table -> (q [B,n], Y or None, info)."""
+    a = table.cpu().numpy() if torch.is_tensor(table) else np.asarray(table)
+    q = a[:, :n].copy()
+    info = {k: a[:, n + i].copy() for i, k in enumerate(RESULT_STATS)}
+    for k in ("iterations", "inner_total", "n_accept", "stop", "inner_executed"):
+        info[k] = info[k].astype(np.int64)
+    Y = None
+    if with_Y:
+        Y = a[:, n + len(RESULT_STATS):].copy()
+        if point_shape is not None:
+            Y = Y.reshape((len(a),) + tuple(point_shape))
+    return q, Y, info
+
+
+def result_row_bytes(n, N=0, k=0, with_Y=False):
+    return 8 * (n + len(RESULT_STATS) + (N * k if with_Y else 0))
+
+
+def solve_batch_sharded(graph, T_goals, use_limits=True, params=None, with_Y=False, dst=0, solve_fn=None):
+    """solve_batch over all ranks of the process group (one rank per GPU; without a process group:
+    this process alone).  EVERY rank passes the full batch T_goals [B, ...] (128 B per goal); rank r
+    solves rows shard_range(B, r, world) and the results are gathered on rank `dst` in ONE collective
+    of result_row_bytes() per problem.  Returns (q [B,n], Y [B,N,k] or None, info) on `dst`,
+    (None, None, None) elsewhere.  `solve_fn(T_local) -> dict` replaces the device solve (tests of
+    the rank / shard / gather logic on machines without a GPU)."""
+    T = np.asarray(T_goals, dtype=float)
+    B = T.shape[0]
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    lo, hi = shard_range(B, rank, world)
+    n = graph.robot.n
+    N, k = graph.number_of_nodes(), graph.dim
+    on_gpu = not (dist.is_initialized() and dist.get_backend() != "nccl") and torch.cuda.is_available()
+    if solve_fn is not None:
+        res = solve_fn(T[lo:hi])
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    else:
+        from .solvers.riemannian_solver import _problem_for, solve_batch
+        prob = _problem_for(graph, use_limits, params, None)
+        dev = prob.template.device
+        if prob.device_pipeline:          # prepare -> solve -> recover on the device, results stay there
+            res = prob.template.ik(torch.from_numpy(np.ascontiguousarray(T[lo:hi])).to(dev))
+        else:
+            q, Y, info = solve_batch(graph, T[lo:hi], use_limits=use_limits, params=params)
+            res = dict(info, q=q, x=Y, f=info["f(x)"], inner_total=info["inner_iterations"],
+                       n_accept=np.zeros(len(q)), inner_executed=info["inner_iterations"])
+        if dist.is_initialized() and dist.get_backend() != "nccl":
+            dev = torch.device("cpu")
+    table = gather_rows(pack_results(res, with_Y=with_Y, device=dev), B, dst=dst)
+    if rank != dst:
+        return None, None, None
+    return unpack_results(table, n, with_Y=with_Y, point_shape=(N, k))
 
 
 def barrier():

@@ -103,3 +103,66 @@ def test_bench_refuses_a_wrong_world_size():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--dry-solve", "--gpus", "2"],
                        env=env, timeout=300, capture_output=True, text=True)
     assert r.returncode != 0 and "launcher started 1 rank" in (r.stderr + r.stdout)
+
+
+SHARDED_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["GIK_REPO"])
+sys.path.insert(0, os.path.join(os.environ["GIK_REPO"], "tests"))
+import numpy as np, torch
+from graphik_amd import distributed as gd
+from conftest import make_graph
+sys.path.insert(0, os.environ["GIK_REPO"])
+import bench
+rank, local_rank, world = gd.init_process_group(backend="gloo")
+robot, graph = make_graph("lwa4d")
+rs = np.random.RandomState(5)
+T = robot.fk_batch(-np.pi + 2 * np.pi * rs.rand(203, robot.n))          # every rank holds the full batch
+N, k, n = graph.number_of_nodes(), graph.dim, robot.n
+
+def solve_fn(T_local):            # deterministic stand-in for the device solve, rows = functions of the goal
+    res = bench.dry_solve(T_local, n)
+    key = np.abs(T_local.reshape(len(T_local), -1)).sum(axis=1)
+    res["x"] = np.cos(key[:, None, None] * (1.0 + np.arange(N * k).reshape(1, N, k)))
+    return res
+
+q, Y, info = gd.solve_batch_sharded(graph, T, with_Y=True, solve_fn=solve_fn)
+q2, Y2, info2 = gd.solve_batch_sharded(graph, T, with_Y=False, solve_fn=solve_fn)
+if rank == 0:
+    assert Y2 is None and np.array_equal(q, q2)
+    np.savez(os.environ["GIK_OUT"], q=q, Y=Y, **info)
+else:
+    assert q is None and Y is None and info is None and q2 is None
+'''
+
+
+def _run_sharded(tmp_path, world, port):
+    script = tmp_path / f"sharded_{world}.py"
+    script.write_text(SHARDED_WORKER)
+    out = tmp_path / f"sharded_{world}.npz"
+    env = dict(os.environ, GIK_REPO=REPO, GIK_OUT=str(out), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    if world == 1:
+        subprocess.run([sys.executable, str(script)], check=True, env=env, timeout=300, capture_output=True)
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+        subprocess.run(cmd, check=True, env=env, timeout=600, capture_output=True)
+    return dict(np.load(out))
+
+
+def test_solve_batch_sharded_gathers_q_and_Y(tmp_path):
+    """graphik_amd.distributed.solve_batch_sharded -- the library's multi-GPU solve_batch -- over 2 and 8
+    gloo ranks: the ONE gather returns, row for row, what a single process returns: q [B,n], the
+    statistics and (with_Y) the points Y [B,N,k] (SURVEY 8(e)); ranks other than dst get None."""
+    from graphik_amd.distributed import RESULT_STATS, result_row_bytes
+    one = _run_sharded(tmp_path, 1, 0)
+    assert one["q"].shape == (203, 7) and one["Y"].shape == (203, 18, 3)
+    assert set(RESULT_STATS) <= set(one) and one["iterations"].dtype == np.int64
+    assert result_row_bytes(7, 18, 3, with_Y=True) == 8 * (7 + len(RESULT_STATS) + 54)     # 560 B per problem
+    for world, port in ((2, 29541), (8, 29542)):
+        many = _run_sharded(tmp_path, world, port)
+        assert set(many) == set(one)
+        for key in one:
+            assert np.array_equal(one[key], many[key]), (world, key)

@@ -71,13 +71,14 @@ def _legal_stops(r, maxiter=3000, mingradnorm=0.5e-9, sliced=False):
 
 def test_full_size_c3_ur10_table(torch_cuda):
     """BASELINE configs[2]: UR10 + table_environment() (N = 116, 5612 terms), 4096 random goals on
-    the workgroup-per-goal prepare kernel and the workgroup-per-problem solve kernel (rigid clique in
-    closed form, time slicing: 4096 problems on 256 resident workgroups)."""
+    the workgroup-per-goal prepare kernel and the node-per-lane solve kernel (two wavefronts per problem,
+    rigid clique in closed form, time slicing: 4096 problems on 512 resident workgroups)."""
     from oracle import c_oracle as co
     from graphik_amd.solvers.riemannian_solver import BatchProblem
     robot, graph = make_graph("ur10_table")
     prob = BatchProblem(graph, use_limits=True)
     assert prob.device_pipeline and prob.template.info["is_block"] == 1
+    assert prob.template.info["node_per_lane"] == 2     # the node-per-lane kernel, two wavefronts per problem
     assert prob.template.info["n_clique"] == 106 and prob.template.info["n_slot_terms"] == 47
     B = 4096
     Tg = _goals(robot, B, 0)
@@ -121,8 +122,34 @@ def test_full_size_c4_kuka_share(torch_cuda):
     assert 0.8 < r["inner_total"][:n].sum() / o["inner_total"].sum() < 1.25
 
 
+def test_full_size_c4_kuka_whole_batch(torch_cuda):
+    """BASELINE configs[3] as one GPU sees it when it is alone: all 65536 KUKA goals (round-robin slicing and
+    tail spreading on, ~5 hand-overs per long problem), with an oracle sub-sample of its own: 96 goals spread
+    over the batch (every 683rd), solved on the CPU from the device's initial points."""
+    from oracle import c_oracle as co
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    robot, graph = make_graph("kuka")
+    prob = BatchProblem(graph, use_limits=True)
+    B = 65536
+    Tg = _goals(robot, B, 0)
+    r = _pipeline_twice(torch_cuda, prob, Tg)
+    _legal_stops(r, sliced=True)
+    ok = (r["pos"] < 0.01) & (r["rot"] < 0.01)
+    assert ok.mean() > 0.95 and np.median(r["pos"]) < 5e-4
+    assert 0.04 < (r["stop"] == 1).mean() < 0.12
+    idx = np.arange(0, B, 683)[:96]
+    D, _, _ = prob.assemble(Tg[idx])
+    o = co.rtr_solve_batch(r["Y0"][idx], D, prob.omega, prob.psi_L, prob.psi_U, True, fast=False)
+    assert np.mean((r["f"][idx] < 1e-9) == (o["f(x)"] < 1e-9)) > 0.9
+    assert 0.6 < np.median(r["iterations"][idx]) / np.median(o["iterations"]) < 1.6
+    assert 0.8 < r["inner_total"][idx].sum() / o["inner_total"].sum() < 1.25
+    # the 8192-goal share of an 8-GPU run is rows 0..8191 of the same stream: same answers in either batch
+    r8 = prob.template.ik(torch_cuda.from_numpy(Tg[:8192]).cuda())
+    assert np.array_equal(r8["x"].cpu().numpy(), r["x"][:8192]) and np.array_equal(r8["q"].cpu().numpy(), r["q"][:8192])
+
+
 @pytest.mark.parametrize("B", [8192, 65536])
-@pytest.mark.parametrize("name", ["planar10_limits_pi", "planar10_limits_halfpi"])
+@pytest.mark.parametrize("name", ["planar10_limits_pi", "planar10_limits_halfpi", "planar10_nolimits"])
 def test_full_size_c5_planar(torch_cuda, name, B):
     """BASELINE configs[4]: 10-link planar chain (limits +-pi as in test_chain_2d_new.py, and the
     +-pi/2 variant of test_chain_2d_limits_new.py), the per-GPU share of an 8-GPU run and the whole
@@ -131,19 +158,21 @@ def test_full_size_c5_planar(torch_cuda, name, B):
     from oracle import c_oracle as co
     from graphik_amd.solvers.riemannian_solver import BatchProblem
     robot, graph = make_graph(name)
-    prob = BatchProblem(graph, use_limits=True)
+    use_lim = not name.endswith("nolimits")     # nolimits: the j* kernels (jcost / jgrad / jhess, costs.py:8-58), the
+    prob = BatchProblem(graph, use_limits=use_lim)      # default of test_chain_2d_new.py:59
+    assert (prob.psi_L is None) == (not use_lim)
     Tg = _goals(robot, B, 0)
     r = _pipeline_twice(torch_cuda, prob, Tg)
     _legal_stops(r)
     ok = (r["pos"] < 0.01) & (r["rot"] < 0.01)
-    if name.endswith("_pi"):
+    if name.endswith("_pi") or not use_lim:
         # the reference's own acceptance test (test_chain_2d_new.py:82): every EE position error < 1e-4
         assert ok.mean() > 0.999 and np.percentile(r["pos"], 99) < 1e-4
     else:
         assert ok.mean() > 0.9
     n = 128
     D, _, _ = prob.assemble(Tg[:n])
-    o = co.rtr_solve_batch(r["Y0"][:n], D, prob.omega, prob.psi_L, prob.psi_U, True, fast=False)
+    o = co.rtr_solve_batch(r["Y0"][:n], D, prob.omega, prob.psi_L, prob.psi_U, use_lim, fast=False)
     same = (r["iterations"][:n] == o["iterations"]) & (r["inner_total"][:n] == o["inner_total"])
     assert same.mean() > 0.9, same.mean()
     assert np.mean((r["f"][:n] < 1e-9) == (o["f(x)"] < 1e-9)) > 0.97
@@ -357,6 +386,53 @@ def test_rccl_gather_under_torchrun(torch_cuda):
         cf = d["configs"][name]
         assert cf["value"] > lo and 0 < cf["roofline"]["frac_executed"] <= cf["roofline"]["frac"] < 1, (name, cf)
     assert d["configs"]["c3"]["success_rate"] > 0.88 and d["configs"]["c5"]["success_rate"] > 0.999
+
+
+SHARDED_RCCL = r'''
+import os, sys
+sys.path.insert(0, os.environ["GIK_REPO"]); sys.path.insert(0, os.path.join(os.environ["GIK_REPO"], "tests"))
+import numpy as np, torch
+from graphik_amd import distributed as gd
+from conftest import make_graph
+rank, local_rank, world = gd.init_process_group(backend="nccl")
+robot, graph = make_graph("lwa4d")
+T = robot.fk_batch(-np.pi + 2 * np.pi * np.random.RandomState(9).rand(512, robot.n))
+q, Y, info = gd.solve_batch_sharded(graph, T, with_Y=True)
+import torch.distributed as dist
+np.savez(os.environ["GIK_OUT"], q=q, Y=Y, backend=np.array(dist.get_backend()), **info)
+gd.shutdown()
+'''
+
+
+def test_solve_batch_sharded_over_rccl(torch_cuda, tmp_path):
+    """The library call of SURVEY 8(e): graphik_amd.distributed.solve_batch_sharded under
+    `torch.distributed.run --nproc-per-node 1` with the RCCL backend (all a one-GPU lease allows) returns,
+    through its one all_gather of q + statistics + Y, exactly what solve_batch returns in a process
+    without a process group -- joint angles, points and counters bit for bit."""
+    from graphik_amd import distributed as gd
+    from graphik_amd.solvers.riemannian_solver import solve_batch
+    script = tmp_path / "sharded_rccl.py"
+    script.write_text(SHARDED_RCCL)
+    out = tmp_path / "sharded_rccl.npz"
+    env = dict(os.environ, GIK_REPO=REPO, GIK_OUT=str(out), MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29549", str(script)]
+    r = subprocess.run(cmd, env=env, timeout=600, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = dict(np.load(out))
+    assert str(got["backend"]) == "nccl"
+    robot, graph = make_graph("lwa4d")
+    T = robot.fk_batch(-np.pi + 2 * np.pi * np.random.RandomState(9).rand(512, robot.n))
+    q, Y, info = solve_batch(graph, T)
+    assert np.array_equal(got["q"], q) and np.array_equal(got["Y"], Y)
+    assert np.array_equal(got["iterations"], info["iterations"]) and np.array_equal(got["f"], info["f(x)"])
+    assert np.array_equal(got["pos_err"], info["pos_err"])
+    # ... and without a process group it is solve_batch itself
+    q1, Y1, info1 = gd.solve_batch_sharded(graph, T, with_Y=True)
+    assert np.array_equal(q1, q) and np.array_equal(Y1, Y) and np.array_equal(info1["stop"], info["stop"])
+    assert gd.result_row_bytes(robot.n, 18, 3, with_Y=True) == 560
 
 
 def test_integration_stub_runs(torch_cuda):
