@@ -41,19 +41,22 @@ constexpr int NPT_RS = 4;              // LDS row stride (doubles)
 
 // launch-invariant tables (device pointers; gik_template_create)
 struct NptTabs {
-  const int *node_of_row;          // [128] the caller's node of LDS row r, -1 = none
+  const int *node_of_row;          // [128] the caller's node held by thread slot NS * thread + s, -1 = none
+  const unsigned char *prow_of_slot;   // [128] its row in the point table sh_P (clique nodes: cbase + rank)
   const int *clq_pair_term;        // [n_pairs] target index of clique pair (a < b: clique ranks), p = a n - a (a + 1) / 2 + b - a - 1
   const uint32_t *term_rec;        // [TL][64] row_i | row_j << 8 | kind << 16 | wslot_i << 18 | wslot_j << 25; kind 0 = padding
   const int *term_tgt;             // [TL][64] target index of the lane's term, -1 = padding
   const unsigned short *gather;    // [DEG0 + DEG1][threads] row of the +-t table the thread adds: 2 slot (+t) or 2 slot + 1 (-t);
                                    // padding = the zero row 2 * n_terms
-  const unsigned char *wslot_of_row;   // [128] row of the compact direction table that publishes row r, 255 = none
+  const unsigned char *wslot_of_row;   // [128] (per thread slot) row of the compact direction table that publishes the node, 255 = none
   int n_clq, n_pairs, DEG0, DEG1, n_wrows, TL;
   int clq_euclid;                  // 1: look for point coordinates behind the clique's target distances
   int cbase;                       // first row of the clique (its nodes take rows cbase .. cbase + n_clq - 1, rank = row - cbase)
   int n_rows;                      // rows in use (even)
   int n_terms;                     // slot terms (the first n_terms of the TL * 64 term slots, all evaluated by wavefront 0)
   int term_sync;                   // two waves per problem: 1 = end nodes of slot terms sit in both wavefronts
+  int n_helped;                    // one node per lane: lanes 2 i (i < n_helped) hold the busiest nodes, lane 2 i + 1 gathers the
+                                   // second half of lane 2 i's list (the gather is as long as the longest list of any lane)
 };
 
 // Sum 24 independent per-lane values over the wavefront by transposing exchanges (the scheme of
@@ -109,6 +112,8 @@ struct NptCtx {
   bool live[NS];
   double lm[NS];             // 1.0 / 0.0
   int gnode[NS];
+  int prow[NS];              // element offset of the node's row in sh_P
+  double g_own, g_recv;      // gather: 1.0 if the lane's list is its own node's / if lane + 1 holds the rest of it
   // rigid clique (rows cbase .. cbase + n_clq - 1)
   int n_clq, n_pairs, cbase;
   double n_count;
@@ -263,13 +268,15 @@ struct NptCtx {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int r = NS * tid + s;
-      gnode[s] = r < nt.n_rows ? nt.node_of_row[r] : -1;
+      gnode[s] = r < NPT_MAXN ? nt.node_of_row[r] : -1;
       live[s] = gnode[s] >= 0;
       lm[s] = live[s] ? 1.0 : 0.0;
-      inq[s] = live[s] && r >= cbase && r < cbase + n_clq;
-      crank[s] = inq[s] ? r - cbase : 0;
+      const int pr = live[s] ? (int)nt.prow_of_slot[r] : 0;
+      prow[s] = pr * NPT_RS;
+      inq[s] = live[s] && pr >= cbase && pr < cbase + n_clq;
+      crank[s] = inq[s] ? pr - cbase : 0;
       offc[s] = crank[s] * n_clq - crank[s] * (crank[s] + 1) / 2 - crank[s] - 1;
-      const int ws = r < nt.n_rows ? nt.wslot_of_row[r] : 255;
+      const int ws = live[s] ? nt.wslot_of_row[r] : 255;
       w_addr[s] = ws == 255 ? -1 : ws * NPT_RS;
       rD[s] = 0.0;
       rr[s] = 0.0;
@@ -292,6 +299,11 @@ struct NptCtx {
       t_c[u] = t_a2[u] = 0.0;
 #pragma unroll
       for (int q = 0; q < 3; ++q) t_y[u][q] = 0.0;
+    }
+    {   // helper lanes of the gather (one node per lane)
+      const bool helped = NS == 1 && wave == 0 && (lane >> 1) < nt.n_helped;
+      g_recv = (helped && !(lane & 1)) ? 1.0 : 0.0;
+      g_own = (helped && (lane & 1)) ? 0.0 : 1.0;
     }
     mscale = 1.0;
 #pragma unroll
@@ -362,7 +374,7 @@ struct NptCtx {
   __device__ inline int clique_argmax(const double (&val)[NS], double &best) {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-      if (live[s]) sh_P[(NS * tid + s) * NPT_RS + 3] = inq[s] ? val[s] : -1.0;
+      if (live[s]) sh_P[prow[s] + 3] = inq[s] ? val[s] : -1.0;
     block_sync();
     double b = -1.0;
     int arg = 0;
@@ -393,7 +405,7 @@ struct NptCtx {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const double zero[3] = {0.0, 0.0, 0.0};
-      if (live[s]) put3(sh_P, (NS * tid + s) * NPT_RS, zero);
+      if (live[s]) put3(sh_P, prow[s], zero);
       if (!ok) {
         rr[s] = 0.0;
         Xr[s][0] = Xr[s][1] = Xr[s][2] = 0.0;
@@ -419,7 +431,7 @@ struct NptCtx {
     if (!(m2 > 1e-6 * m1)) return false;    // collinear
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-      if (live[s]) sh_P[(NS * tid + s) * NPT_RS] = x[s];
+      if (live[s]) sh_P[prow[s]] = x[s];
     block_sync();
     const double x2 = sh_P[(cbase + a2) * NPT_RS], y2 = sqrt(m2);
 #pragma unroll
@@ -431,7 +443,7 @@ struct NptCtx {
     if (!(m3 > 1e-6 * m1)) return false;    // coplanar
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-      if (live[s]) sh_P[(NS * tid + s) * NPT_RS + 1] = y[s];
+      if (live[s]) sh_P[prow[s] + 1] = y[s];
     block_sync();
     const double x3 = sh_P[(cbase + a3) * NPT_RS], y3 = sh_P[(cbase + a3) * NPT_RS + 1], z3 = sqrt(m3);
     double c[3] = {0.0, 0.0, 0.0};
@@ -452,7 +464,7 @@ struct NptCtx {
       Xr[s][1] = q * fma(-c[1], inv_n, y[s]);
       Xr[s][2] = q * fma(-c[2], inv_n, z[s]);
       rr[s] = fma(Xr[s][2], Xr[s][2], fma(Xr[s][1], Xr[s][1], Xr[s][0] * Xr[s][0]));
-      if (inq[s]) put3(sh_P, (NS * tid + s) * NPT_RS, Xr[s]);
+      if (inq[s]) put3(sh_P, prow[s], Xr[s]);
     }
     block_sync();
     double bad = 0.0;
@@ -483,7 +495,7 @@ struct NptCtx {
   __device__ inline double cost(const double (&x)[NE]) {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-      if (live[s]) put3(sh_P, (NS * tid + s) * NPT_RS, &x[3 * s]);
+      if (live[s]) put3(sh_P, prow[s], &x[3 * s]);
     block_sync();
     double f = 0.0;
     if (wave == 0) {
@@ -592,6 +604,7 @@ struct NptCtx {
     // of one; a DS instruction costs a lone wavefront 10-16 issue cycles, so the last group is as
     // short as the list allows: GG = 3 reads 9 entries for the table scene's 9, GG = 4 would read 12).
     // (the one-wavefront layout has no registers to spare for that: it reads and sums group by group)
+    double ga[3] = {0.0, 0.0, 0.0};        // (one node per lane) the lane's list, which may be half of its neighbour's
     constexpr int GG = 3, NGRP = (2 * NG + GG - 1) / GG;
     constexpr bool BATCH = false;      // (measured on the two-wavefront layout: all reads up front 4.5 k cycles per product, group by group 4.1 k)
     double t[NGRP * GG][3];
@@ -620,7 +633,7 @@ struct NptCtx {
           if (e < 2 * NG) {
             if constexpr (NS == 1) {
 #pragma unroll
-              for (int q = 0; q < 3; ++q) acc[0][q] += t[e][q];
+              for (int q = 0; q < 3; ++q) ga[q] += t[e][q];
             } else {
               const double m0 = e < n0 ? 1.0 : 0.0, m1 = 1.0 - m0;     // (uniform)
 #pragma unroll
@@ -632,6 +645,12 @@ struct NptCtx {
           }
         }
       }
+    }
+    if constexpr (NS == 1) {
+      // an even lane's node also owns what the odd lane next to it gathered (quad_perm [1,1,3,3]); a helper
+      // lane's own node carries no slot terms
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[0][q] += fma(g_recv, dpp_f64<0xF5>(ga[q]), g_own * ga[q]);
     }
   }
 
@@ -851,7 +870,7 @@ struct NptCtx {
           for (int q = 0; q < 3; ++q) hq[s][q] = fma(cS[s], Sv[q], wm[s][q] * cw[s]);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NS > 1) __builtin_amdgcn_sched_barrier(0);
       {   // - 2 T3_q - U3_q (+ R3_q): the same vector for every node of the clique
         const double c0 = mo(9) + mo(12), c1 = mo(10) + mo(13), c2 = mo(11) + mo(14);
 #pragma unroll
@@ -862,7 +881,7 @@ struct NptCtx {
           hq[s][2] = fma(cmk, c2, hq[s][2]);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NS > 1) __builtin_amdgcn_sched_barrier(0);
       {   // Ms = M + M^T (xx xy xz yy yz zz): (Ms y~)_q, tr M; and (Syy w)_q, y~_q g
         const double M0 = mo(3), M1 = mo(4), M2 = mo(5), M3 = mo(6), M4 = mo(7), M5 = mo(8);
         const double s_yw = 0.5 * ((M0 + M3) + M5);
@@ -881,7 +900,7 @@ struct NptCtx {
           z[s][2] = fma(y[2], gg, z2);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NS > 1) __builtin_amdgcn_sched_barrier(0);
       if (lowrank) {      // - (P X_i)_q,  P[q][a] at 15 + 3 a + q
         const double P0 = mo(15), P1 = mo(16), P2 = mo(17), P3 = mo(18), P4 = mo(19), P5 = mo(20), P6 = mo(21),
                      P7 = mo(22), P8 = mo(23);
@@ -910,34 +929,19 @@ struct NptCtx {
   }
 
   // (D w)_i, dense: only for targets that are not distances of points (an arbitrary D_goal through
-  // gik_solve_batch, collinear or coplanar cliques).  O(n) per node and product: the direction rows of
-  // the clique are broadcast from their owners' registers, one rank per step (v_readlane; with two
-  // wavefronts through the reduction scratch behind a barrier).
+  // gik_solve_batch, collinear or coplanar cliques).  O(n) per node and product.  The direction rows
+  // of all nodes are published in the point table's place -- sh_P is only read between a cost() and the
+  // commit() that follows it, and every cost() rewrites it -- and walked like the clique in cost().
   __device__ inline void clique_dw(const double (&W)[NE], double (&acc)[NS][3]) {
+    block_sync();
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (live[s]) put3(sh_P, prow[s], &W[3 * s]);
+    block_sync();
     for (int m = 0; m < n_clq; ++m) {
       const int offm = tri_off(m, n_clq);
-      const int r = cbase + m;                       // row -> (thread, slot)
-      const int src_t = r / NS, src_s = r % NS;
-      double e[3], wm[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        e[q] = W[q];
-        if constexpr (NS == 2) e[q] = src_s ? W[NE - 3 + q] : W[q];
-      }
-      if constexpr (NW == 1) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) wm[q] = readlane_f64(e[q], src_t);
-      } else {
-        double *buf = sh_red + red_buf * (NW * 32);
-        if (tid == src_t) {
-#pragma unroll
-          for (int q = 0; q < 3; ++q) buf[q] = e[q];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 3; ++q) wm[q] = buf[q];
-        red_buf ^= 1;
-      }
+      double wm[3];
+      row3(sh_P, (cbase + m) * NPT_RS, wm);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const double dg = (inq[s] && m != crank[s]) ? sh_ctg[pair_index(s, m, offm)] : 0.0;

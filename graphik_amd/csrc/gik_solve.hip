@@ -1160,7 +1160,7 @@ struct gik_template {
   // node-per-lane path (rtr_npt_kernel): trust-region solves and the known-answer entry points of
   // 3-D graphs beyond one wavefront's 64 unknowns; the workgroup tables above stay (ConjugateGradient)
   bool is_npt = false;
-  gik::NptTabs nt = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  gik::NptTabs nt = {};
   const gik::NptVariant *npt_variant = nullptr;
   size_t npt_smem = 0;
   int npt_waves_per_cu = 1;
@@ -1338,7 +1338,8 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   std::vector<int> npt_node_of_row, npt_term_tgt, npt_pair_term;
   std::vector<uint32_t> npt_term_rec;
   std::vector<unsigned short> npt_gather;
-  std::vector<unsigned char> npt_wslot;
+  std::vector<unsigned char> npt_wslot, npt_prow;
+  int npt_n_helped = 0;
   if (is_block) {
     // A rigid clique -- a set of nodes every pair of which is tied by an equality term (the
     // anchors of a scene with many obstacles) -- is taken out of the slot tables and handled in
@@ -1494,16 +1495,48 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
       auto by_deg = [&](int a, int b) { return sdeg[a] > sdeg[b]; };
       std::stable_sort(cl_busy.begin(), cl_busy.end(), by_deg);
       std::stable_sort(others.begin(), others.end(), by_deg);
+      // nrow[v]: row of node v in the point table; npt_node_of_row[t]: node held by thread slot t
       npt_node_of_row.assign(NPT_MAXN, -1);
-      std::vector<int> nrow(N, -1);
+      npt_prow.assign(NPT_MAXN, 0);
+      std::vector<int> nrow(N, -1), nslot(N, -1);
       int n_rows = 0;
+      npt_n_helped = 0;
       if (npt_two_waves) {
         npt_cbase = (int)others.size();
         int r = 0;
-        for (int v : others) { npt_node_of_row[r] = v; nrow[v] = r++; }
-        for (int v : cl_busy) { npt_node_of_row[r] = v; nrow[v] = r++; }
-        for (int v : cl_idle) { npt_node_of_row[r] = v; nrow[v] = r++; }
+        for (int v : others) nrow[v] = r++;
+        for (int v : cl_busy) nrow[v] = r++;
+        for (int v : cl_idle) nrow[v] = r++;
         n_rows = r;
+        // thread slots: the nodes that carry slot terms on the even lanes 0, 2, ... of wavefront 0, each with a
+        // clique node WITHOUT slot terms next to it (its helper in the gather); everything else behind
+        std::vector<int> busy(others.begin(), others.end());
+        busy.insert(busy.end(), cl_busy.begin(), cl_busy.end());
+        busy.erase(std::remove_if(busy.begin(), busy.end(), [&](int v) { return sdeg[v] == 0; }), busy.end());
+        std::stable_sort(busy.begin(), busy.end(), by_deg);
+        std::vector<char> placed(N, 0);
+        int slot = 0;
+        size_t ih = 0;
+        const bool can_help = 2 * busy.size() <= (size_t)WAVE && cl_idle.size() >= busy.size();
+        for (int v : busy) {
+          npt_node_of_row[slot] = v;
+          nslot[v] = slot++;
+          placed[v] = 1;
+          if (can_help) {
+            const int h = cl_idle[ih++];
+            npt_node_of_row[slot] = h;
+            nslot[h] = slot++;
+            placed[h] = 1;
+          }
+        }
+        npt_n_helped = can_help ? (int)busy.size() : 0;
+        for (int pass = 0; pass < 3; ++pass)
+          for (int v : (pass == 0 ? others : (pass == 1 ? cl_busy : cl_idle)))
+            if (!placed[v]) {
+              npt_node_of_row[slot] = v;
+              nslot[v] = slot++;
+              placed[v] = 1;
+            }
       } else {
         npt_cbase = 0;
         size_t ib = 0, ii = 0;
@@ -1512,7 +1545,6 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
           int v;
           if ((want_busy && ib < cl_busy.size()) || ii >= cl_idle.size()) v = cl_busy[ib++];
           else v = cl_idle[ii++];
-          npt_node_of_row[r] = v;
           nrow[v] = r;
         }
         const int start = (n_clq + 1) & ~1;
@@ -1520,20 +1552,26 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
         n_rows = n_clq;
         for (size_t q = 0; q < others.size(); ++q) {
           const int r = even_only ? start + 2 * (int)q : n_clq + (int)q;
-          npt_node_of_row[r] = others[q];
           nrow[others[q]] = r;
           n_rows = r + 1;
         }
+        for (int v = 0; v < N; ++v) {      // thread slot = row
+          npt_node_of_row[nrow[v]] = v;
+          nslot[v] = nrow[v];
+        }
       }
+      for (int v = 0; v < N; ++v) npt_prow[nslot[v]] = (unsigned char)nrow[v];
       npt_n_rows = (n_rows + 1) & ~1;
       // compact direction table: one row per node that carries slot terms
       npt_wslot.assign(NPT_MAXN, 255);
       int n_wrows = 0;
       npt_term_sync = 0;
-      for (int r = 0; r < NPT_MAXN; ++r)
-        if (npt_node_of_row[r] >= 0 && sdeg[npt_node_of_row[r]]) {
-          npt_wslot[r] = (unsigned char)n_wrows++;
-          if (npt_two_waves && r >= WAVE) npt_term_sync = 1;
+      std::vector<int> wslot_of_node(N, 255);
+      for (int t = 0; t < NPT_MAXN; ++t)
+        if (npt_node_of_row[t] >= 0 && sdeg[npt_node_of_row[t]]) {
+          wslot_of_node[npt_node_of_row[t]] = n_wrows;
+          npt_wslot[t] = (unsigned char)n_wrows++;
+          if (npt_two_waves && t >= WAVE) npt_term_sync = 1;
         }
       const int Tn = (int)nc_term.size();
       const int TLn = Tn <= 64 ? 1 : 4;
@@ -1551,17 +1589,24 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
           const int t = nc_term[q], i = d->term_i[t], j = d->term_j[t], kind = d->term_kind[t];
           const int ri = nrow[i], rj = nrow[j];
           npt_term_rec[q] = (uint32_t)ri | ((uint32_t)rj << 8) | ((uint32_t)kind << 16) |
-                            ((uint32_t)npt_wslot[ri] << 18) | ((uint32_t)npt_wslot[rj] << 25);
+                            ((uint32_t)wslot_of_node[i] << 18) | ((uint32_t)wslot_of_node[j] << 25);
           npt_term_tgt[q] = t;
           // term slot q = u * 64 + lane: the order of nc_term (= the reference's edge order)
-          glist[ri].push_back({j, kind, q, 0});
-          glist[rj].push_back({i, kind, q, 1});
+          glist[nslot[i]].push_back({j, kind, q, 0});
+          glist[nslot[j]].push_back({i, kind, q, 1});
         }
         int deg[2] = {0, 0};
-        for (int r = 0; r < NPT_MAXN; ++r) {
+        for (int r = 0; r < NPT_MAXN; ++r)
           std::stable_sort(glist[r].begin(), glist[r].end(), [](const GEnt &a, const GEnt &b) {
             return a.other != b.other ? a.other < b.other : a.kind < b.kind;
           });
+        for (int i = 0; i < npt_n_helped; ++i) {      // the second half of a busy node's list moves to its helper
+          std::vector<GEnt> &own = glist[2 * i], &hlp = glist[2 * i + 1];
+          const size_t keep = (own.size() + 1) / 2;
+          hlp.assign(own.begin() + keep, own.end());
+          own.resize(keep);
+        }
+        for (int r = 0; r < NPT_MAXN; ++r) {
           const int sl = NSn == 1 ? 0 : (r & 1);
           deg[sl] = std::max(deg[sl], (int)glist[r].size());
         }
@@ -1577,9 +1622,11 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
                 (unsigned short)((glist[r][e].slot << 1) | glist[r][e].neg);
         }
         npt_pair_term.clear();
+        std::vector<int> node_at_row(NPT_MAXN, 0);
+        for (int v = 0; v < N; ++v) node_at_row[nrow[v]] = v;
         for (int a = 0; a < n_clq; ++a)
           for (int b = a + 1; b < n_clq; ++b)
-            npt_pair_term.push_back(eqterm[(size_t)npt_node_of_row[npt_cbase + a] * N + npt_node_of_row[npt_cbase + b]]);
+            npt_pair_term.push_back(eqterm[(size_t)node_at_row[npt_cbase + a] * N + node_at_row[npt_cbase + b]]);
         npt_n_wrows = n_wrows;
         npt_n_terms = Tn;
       }
@@ -1774,6 +1821,8 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     t->nt.term_tgt = upload(t, npt_term_tgt.data(), npt_term_tgt.size(), ok);
     t->nt.gather = upload(t, npt_gather.data(), npt_gather.size(), ok);
     t->nt.wslot_of_row = upload(t, npt_wslot.data(), npt_wslot.size(), ok);
+    t->nt.prow_of_slot = upload(t, npt_prow.data(), npt_prow.size(), ok);
+    t->nt.n_helped = npt_n_helped;
     t->nt.n_clq = n_clq;
     t->nt.n_pairs = (int)npt_pair_term.size();
     t->nt.DEG0 = npt_DEG0;
