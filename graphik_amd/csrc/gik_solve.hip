@@ -1148,8 +1148,9 @@ struct gik_template {
   int dbg;            // SolveArgs::dbg
   int wpc_override;   // persistent waves per CU, 0 = automatic
   int slice_its;      // time slice of the block kernel in outer iterations, 0 = off
-  int npt_slice_its = 128;   // ... of the node-per-lane kernel
+  int npt_slice_its = 192;   // ... of the node-per-lane kernel
   int wave_slice_its; // round-robin slice of the wavefront kernel (large batches), 0 = off
+  bool wave_slice_auto = true;   // ... scaled with the queue depth (gik_solve_batch)
   int wave_slice_cycles = 2000000;   // ... and its shortest duration (GIK_SLICE_CYCLES)
   int waves_per_cu;  // resident solve wavefronts per CU (from the occupancy query)
   size_t smem_bytes;
@@ -1683,12 +1684,15 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   t->slice_its = d->slice_outer_its < 0 ? 256 : d->slice_outer_its;
   // node-per-lane kernel, table scene, 4096 goals (round 4): slice 0 / 48 / 96 / 256 / 600 -> 1689 / 1896 / 1894 / 1861 /
   // 1774 solves/s (two problems per CU: 512 slots, a third of the requeues of the workgroup kernel)
-  t->npt_slice_its = d->slice_outer_its < 0 ? 128 : d->slice_outer_its;
+  // HBM traffic per launch (PMC): 603 MB at 128 = 2.9 x the algorithmic 207 MB (every resume re-reads the problem's 45 KB of
+  // clique targets); 192 is the compromise
+  t->npt_slice_its = d->slice_outer_its < 0 ? 192 : d->slice_outer_its;
   // developer overrides, read once here (never inside a batch call)
   if (const char *e = getenv("GIK_WAVES_PER_CU")) t->wpc_override = std::max(1, atoi(e));
   // wavefront kernel: 256 ... 32 iterations per slice give the same time (NOTEBOOK 8.3); the longest of
   // them moves the fewest problems through HBM (KUKA 65536: 118 k hand-overs of ~1.5 KB instead of 562 k at 64)
   t->wave_slice_its = d->slice_outer_its < 0 ? 256 : d->slice_outer_its;
+  t->wave_slice_auto = d->slice_outer_its < 0 && !getenv("GIK_SLICE");   // (an explicit length is taken literally)
   if (const char *e = getenv("GIK_SLICE")) t->slice_its = t->npt_slice_its = t->wave_slice_its = std::max(0, atoi(e));
   if (const char *e = getenv("GIK_SLICE_CYCLES")) t->wave_slice_cycles = std::max(0, atoi(e));
   t->d_slot_meta = nullptr;
@@ -2317,7 +2321,14 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   if (slice > 0 || mig) {
     const size_t cap = mig ? (size_t)B + (size_t)grid + 64 : (size_t)B * (size_t)(t->p.maxiter / slice + 1);
     // wavefront kernel: round-robin slicing (slice length: the handle's wave_slice_its)
-    const int wslice = (mig && !(a.dbg & 1024)) ? t->wave_slice_its : 0;
+    // Slice length grows with the queue: 256 iterations up to 8 problems per wave, 4 x that from 32 per wave on.
+    // A hand-over moves ~4.5 KB through HBM (point, state, the targets re-read; PMC, round 3: 624 MB per 65536-goal
+    // KUKA launch = 6.3 x the algorithmic bytes at 118 k hand-overs); measured round 4 (tools/slice_scan.py), KUKA
+    // 65536: slice 256 / 512 / 1024 / 2048 -> 501.5 / 500.9 / 510.6 / 514.0 ms and 118 k / 51 k / 19 k / 7.5 k
+    // hand-overs; KUKA 8192: 145.5 / 147.7 / 161.6 ms -- short queues want the short slice.
+    int wslice = (mig && !(a.dbg & 1024)) ? t->wave_slice_its : 0;
+    if (wslice > 0 && t->wave_slice_auto && (long long)B > 8LL * grid)
+      wslice = (int)std::min<long long>(4LL * wslice, (long long)wslice * B / (8LL * grid));
     const size_t ycap = wslice > 0 ? (size_t)16 * B + 8192 : 0;
     const size_t off_simd = 32, off_seq = off_simd + (mig ? sizeof(int) * MIG_SIMDS : 0), off_ids = off_seq + cap * 4,
                  off_state = (off_ids + cap * 4 + 15) & ~(size_t)15,

@@ -76,7 +76,7 @@ typedef struct {
    * gik_template_create, as developer overrides of these fields)                             */
   int32_t waves_per_cu;      /* persistent solve waves (workgroups) per CU; 0 = automatic      */
   int32_t slice_outer_its;   /* time slice in outer iterations: a problem yields its slot to whatever
-                                waits after that many; -1 = default (256; node-per-lane kernel 128; on the
+                                waits after that many; -1 = default (256; node-per-lane kernel 192; on the
                                 wavefront kernel only for batches beyond the resident waves), 0 = off */
   int32_t debug_flags;       /* developer flags (gik_solve.hip: SolveArgs::dbg); 16 = rerun tCG
                                 after a rejected step instead of resuming from the checkpoint;

@@ -22,7 +22,7 @@ import sys
 from collections import defaultdict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P = os.path.join(REPO, "gpurun_out", "prof_" + tag)
 out = os.path.join(REPO, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -48,7 +48,7 @@ for k, cs in summary.items():
     cs["_dispatches"] = len(next(iter(per[k].values())))
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc_per_launch.json"), "w"), indent=1)
 
-solve = next(k for k in summary if "rtr_wave_kernel" in k or "rtr_block_kernel" in k)
+solve = next(k for k in summary if "rtr_wave_kernel" in k or "rtr_block_kernel" in k or "rtr_npt_kernel" in k)
 fetch = summary[solve]["FETCH_SIZE"] * 1024 * 2
 write = summary[solve]["WRITE_SIZE"] * 1024
 json.dump({"kernel": solve, "bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch,
@@ -71,6 +71,10 @@ if "SQ_INSTS_VALU" in s:
     print("per tCG iteration: VALU %.1f  LDS %.1f  MFMA %.2f  SALU %.1f  wave cycles %.0f  (hv %d)" % (
         s["SQ_INSTS_VALU"] / hv, s["SQ_INSTS_LDS"] / hv, s.get("SQ_INSTS_MFMA", 0) / hv,
         s["SQ_INSTS_SALU"] / hv, s["SQ_WAVE_CYCLES"] / hv, hv))
+    # SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* count quad-cycles; per product and WAVEFRONT (a problem = 1, 2 or 8 of them)
+    wpp = 8 if "rtr_block" in solve else (2 if "rtr_npt_kernel<1, 1, 2>" in solve or "rtr_npt_kernel<4, 1, 2>" in solve else 1)
+    print("wavefronts per problem %d: %.0f wave cycles per product and wavefront (batch average, co-resident problems included), "
+          "VALU-active %.0f" % (wpp, 4 * s["SQ_WAVE_CYCLES"] / hv / wpp, 4 * s["SQ_ACTIVE_INST_VALU"] / hv / wpp))
     print("VALU active / wave cycles %.2f   LDS bank conflict / LDS active %.2f" % (
         s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"],
         s["SQ_LDS_BANK_CONFLICT"] / max(s.get("SQ_LDS_IDX_ACTIVE", 1), 1)))
