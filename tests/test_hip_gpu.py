@@ -142,7 +142,7 @@ def test_trajectory_planar_identical_to_oracle(torch_cuda, name):
 def _hip_traces(d, path):
     from graphik_amd.engine import Template
     T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=3, use_limits=True,
-                               params={"force_block_path": int(path == "block")})
+                               params={"force_block_path": {"wave": 0, "block": 1, "npt": 2}[path]})
     r = T.solve(d["Y_init"], T.targets_from_D(d["D_goal"]), trace_cap=48)
     tr = {k: v.cpu().numpy() for k, v in r["trace"].items()}
     return r, [{k: tr[k][g] for k in tr} for g in range(len(d["seed"]))]
@@ -201,7 +201,7 @@ def test_trajectory_prefix_3d(torch_cuda, name, path):
     assert k_hip.sum() >= 0.85 * k_ref.sum(), (k_hip, k_ref)
 
 
-@pytest.mark.parametrize("path", ["wave", "block"])
+@pytest.mark.parametrize("path", ["wave", "block", "npt"])
 @pytest.mark.parametrize("name", SCENARIOS_3D)
 def test_finals_statistical_3d(torch_cuda, name, path):
     """End-to-end parity of the recovered joint configurations (same IK branch,
@@ -218,6 +218,14 @@ def test_finals_statistical_3d(torch_cuda, name, path):
         nothing beyond the self-motion scale (0.2 rad) except where the oracle leaves the
         reference's branch as well;
       * convergence class per goal, iteration counts and EE errors as before.
+    Round 4 (tools/parity_paths.py -> profiles/r04_parity_by_kernel_path.json) pinned where the wavefront
+    kernel's larger drift comes from: the workgroup and node-per-lane kernels form s = y . (W_i - W_j) per
+    edge and then s y, as costs.py:186-203 does, so the Gauss-Newton part's round-off lies along y; the
+    wavefront kernel's column form multiplies by the rows of B = 2 a y y^T + c I and never forms s.  KUKA
+    median |dq|: reference pair 3.0e-3, oracle 2.0e-3, workgroup 2.6e-3, node-per-lane 2.5e-3, wavefront
+    8.4e-3.  So the bar is 2x on the two kernels that form s and stays 3x on the wavefront kernel, where
+    forming s costs more than it returns (three lanes share a node: +10 % per product measured for the row
+    form, rounds 1 and 3, against -5 % products).
     The measured distributions are written to gpurun_out/parity_report.json."""
     from oracle import c_oracle as co
     from parity_util import report, wrap_abs
@@ -262,9 +270,12 @@ def test_finals_statistical_3d(torch_cuda, name, path):
         # upper quartile against the upper quartile:
         both = conv & (d["loop_f_sol"] < 1e-9)
         for qt in (50, 75):
-            bar = 3 * max(np.percentile(dq_orc[conv], qt), np.percentile(dq_ref[both], qt))
+            bar = (3 if path == "wave" else 2) * max(np.percentile(dq_orc[conv], qt), np.percentile(dq_ref[both], qt))
             assert np.percentile(dq[conv], qt) <= bar, (qt, np.percentile(dq[conv], qt), bar)
-        assert np.all((dq[conv] < 0.2) | (dq_orc[conv] > 0.05)), (dq, dq_orc)
+        # nothing beyond the self-motion scale, except on goals where the oracle or the reference's OWN second path
+        # leaves the numpy path's branch as well (LWA4D goal 14: reference pair 0.195 rad apart, node-per-lane
+        # kernel 0.200, oracle 0.035)
+        assert np.all((dq[conv] < 0.2) | (dq_orc[conv] > 0.05) | (dq_ref[conv] > 0.05)), (dq, dq_orc, dq_ref)
 
 
 @pytest.mark.parametrize("name", SCENARIOS_3D)
@@ -296,17 +307,23 @@ def test_gradient_roundoff_is_horizontal(torch_cuda, name):
         assert np.abs(G[b].sum(axis=0)).max() < 1e-12 * nrm   # translation-free as well
 
 
-def test_effort_parity_ur10(torch_cuda):
+@pytest.mark.parametrize("path", ["wave", "block", "npt"])
+def test_effort_parity_ur10(torch_cuda, path):
     """Same work as the reference's algorithm, not only the same answers: on random UR10 goals no
     tCG solve runs into maxinner (the reference's never do; a search direction that keeps the
     vertical round-off of the gradient does, late in a solve, in one solve out of five), outer
     iterations agree in distribution and the Hessian products stay within 12 % of the oracle's
     (measured +8 %: the column-form product puts its round-off outside range(J^T), NOTEBOOK 2; the
-    bound was 15 % in round 2)."""
+    bound was 15 % in round 2).  The kernels that form s = y . w per edge like the reference -- workgroup and
+    node-per-lane -- measure +2 % (1024 goals per arm, profiles/r04_parity_by_kernel_path.json: wavefront
+    +6.6 / +7.1 / +7.9 %, workgroup +5.1 / +1.9 / +2.2 %, node-per-lane +3.5 / +1.6 / +2.1 % on KUKA / LWA4D /
+    UR10) and are held to 6 %; the wavefront kernel keeps 12 %: forming s there needs a three-lane sum per
+    term (+25 % instructions) or whole-row gathers (+10 % cycles, measured) to save 5 % of the products."""
     from oracle import c_oracle as co
     from graphik_amd.solvers.riemannian_solver import BatchProblem
     robot, graph = make_graph("ur10")
-    prob = BatchProblem(graph, use_limits=True)
+    prob = BatchProblem(graph, use_limits=True, params={"force_block_path": {"wave": 0, "block": 1, "npt": 2}[path]})
+    assert prob.template.info["is_block"] == int(path != "wave")
     B = 192
     rng = np.random.RandomState(3)
     Tg = robot.fk_batch(-np.pi + 2 * np.pi * rng.rand(B, robot.n))
@@ -322,7 +339,7 @@ def test_effort_parity_ur10(torch_cuda):
     hv_o = np.array([x["inner_total"] for x in o])
     assert np.array_equal(its < 3000, its_o < 3000)
     assert 0.9 < np.median(its) / np.median(its_o) < 1.1
-    assert 0.95 < hv.sum() / hv_o.sum() < 1.12, (hv.sum(), hv_o.sum())
+    assert 0.95 < hv.sum() / hv_o.sum() < (1.12 if path == "wave" else 1.06), (hv.sum(), hv_o.sum())
 
 
 # ---- batched pipeline -------------------------------------------------------------------------
