@@ -188,7 +188,7 @@ def cpu_baseline(prob, T_goal, Y0_h, B, args):
     def run(ns, nthreads):
         D, _, _ = prob.assemble(T_goal[:ns])
         t0 = time.perf_counter()
-        o = co.rtr_solve_batch(Y0_h[:ns], D, prob.omega, prob.psi_L, prob.psi_U, True,
+        o = co.rtr_solve_batch(Y0_h[:ns], D, prob.omega, prob.psi_L, prob.psi_U, prob.psi_L is not None,
                                nthreads=nthreads, fast=True)
         dt = time.perf_counter() - t0
         return dt, int(o["inner_total"].sum())
@@ -299,7 +299,7 @@ class Bench:
         }
 
     def measure(self, cfg, robot_name, total, scaling, steps, warmup, serving_streams=0,
-                cpu=False, n_streams=1, intended=False, seed=None):
+                cpu=False, n_streams=1, intended=False, seed=None, use_limits=True):
         if self.dry:
             return self.measure_dry(cfg, robot_name, total, scaling, steps, warmup)
         args, torch, gd, dev, rank, world = self.args, self.torch, self.gd, self.dev, self.rank, self.world
@@ -316,7 +316,7 @@ class Bench:
             N, k = len(anch.free), 3
             T = anch.template.T + len(anch.pin)              # terms the Hessian product sees
         else:
-            prob = BatchProblem(graph, use_limits=True, device=dev)
+            prob = BatchProblem(graph, use_limits=use_limits, device=dev)
             N, k, T = graph.number_of_nodes(), graph.dim, prob.template.T
         tpl = prob.template
         on_device = prob.device_pipeline
@@ -573,7 +573,9 @@ class Bench:
                 "min_clearance_of_converged_m": float(clear[conv].min()) if conv.any() else None}
             out["config"]["workload"] += " [--intended: fixed-anchor formulation, not the BASELINE semantics]"
             out["roofline"]["kernel"] = "rtr_wave_kernel<3,9,anchored>"
-        if cpu and not args.no_cpu_baseline and world == 1 and prob.psi_L is not None and anch is None:   # rank 0, single-GPU runs
+        if not use_limits:
+            out["config"]["workload"] += " [use_limits=False: the j* kernels, costs.py:8-58]"
+        if cpu and not args.no_cpu_baseline and world == 1 and anch is None:   # rank 0, single-GPU runs
             out["cpu_baseline"] = cpu_baseline(prob, T_goal, Y0_h, B, args)
         return out
 
@@ -624,11 +626,13 @@ def main():
         extra = {}
         plan = [("c3", "ur10_table", 4096 * b.world, "weak", 2, 1),
                 ("c4", "kuka", 65536, "strong", 3, 1),
-                ("c5", "planar10", 65536, "strong", 5, 1)]
+                ("c5", "planar10", 65536, "strong", 5, 1),
+                ("c5_nolimits", "planar10", 65536, "strong", 5, 1)]      # use_limits=False & True
         if b.world == 1:
             plan.insert(2, ("c4_share_of_8", "kuka", 8192, "strong", 5, 1))
         for name, rb, tot, sc, st, wu in plan:
-            o = b.measure(name[:2], rb, tot, sc, st, wu, cpu=(name != "c4_share_of_8"))
+            o = b.measure(name[:2], rb, tot, sc, st, wu, cpu=(name != "c4_share_of_8"),
+                          use_limits=(name != "c5_nolimits"))
             if b.rank == 0:
                 extra[name] = brief(o)
         # the headline on seeds 0-3: `value` stays seed 0; a 4096-goal batch is as long as

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -1123,11 +1124,13 @@ struct gik_template {
   struct CounterSlot {
     hipEvent_t done = nullptr;
     bool pending = false;
+    bool in_use = false;     // handed to a call that has not recorded `done` yet
   };
   std::vector<CounterSlot> counter_slot;   // [kCounterRing]
   unsigned next_counter = 0;
   int counter_ring = 256;   // slots in use (GIK_COUNTER_RING at creation: tests shrink it to force wraps)
-  std::mutex call_mutex;    // counter ring + time-slicing pool: held from slot hand-out to event record
+  std::mutex call_mutex;    // counter ring + time-slicing pool: held for the slot hand-out and the hand-back only
+                            // (a slot marked in_use belongs to its call: blocking work happens outside the lock)
   std::mutex ev_mutex;      // ev_solve0 / ev_solve1 (anchored templates)
   int clique_mode = 0;      // gik_template_desc::clique_closed_form as resolved at creation
   // time-slicing workspaces (re-queue ring + paused state), a small pool handed out round-robin;
@@ -1137,6 +1140,7 @@ struct gik_template {
     size_t bytes = 0;
     hipEvent_t done = nullptr;
     bool pending = false;
+    bool in_use = false;     // handed to a call that has not recorded `done` yet (only its owner touches the slot)
   };
   static constexpr int kSlicePool = 32;
   SliceWs slice_ws[kSlicePool];
@@ -2133,8 +2137,11 @@ int gik_anchored_ik_batch(const gik_template *anch, const gik_template *base, co
   {
     std::lock_guard<std::mutex> lock(ma->ev_mutex);
     (void)hipEventRecord(ma->ev_solve0, (hipStream_t)stream);
-    rc = gik_solve_batch(anch, Y_free, goal, B, Y_free, d_stats, nullptr, stream);
-    if (rc) return rc;
+  }
+  rc = gik_solve_batch(anch, Y_free, goal, B, Y_free, d_stats, nullptr, stream);     // (not under ev_mutex: other
+  if (rc) return rc;                                                                // threads launch meanwhile)
+  {
+    std::lock_guard<std::mutex> lock(ma->ev_mutex);
     (void)hipEventRecord(ma->ev_solve1, (hipStream_t)stream);
   }
   hipLaunchKernelGGL(anch_gather_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, g);
@@ -2145,10 +2152,16 @@ int gik_anchored_ik_batch(const gik_template *anch, const gik_template *base, co
 double gik_anchored_last_solve_ms(const gik_template *anch) {
   if (!anch || !anch->ev_solve0) return -1.0;
   float ms = -1.0f;
-  std::lock_guard<std::mutex> lock(const_cast<gik_template *>(anch)->ev_mutex);
-  if (hipEventSynchronize(anch->ev_solve1) != hipSuccess ||
-      hipEventElapsedTime(&ms, anch->ev_solve0, anch->ev_solve1) != hipSuccess)
+  hipEvent_t e0, e1;
+  {   // the handles under the lock (a record in another thread is not interleaved with this read), the wait outside it
+    std::lock_guard<std::mutex> lock(const_cast<gik_template *>(anch)->ev_mutex);
+    e0 = anch->ev_solve0;
+    e1 = anch->ev_solve1;
+  }
+  if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+    (void)hipGetLastError();      // (a pair recorded by two different concurrent calls has no defined duration)
     return -1.0;
+  }
   return (double)ms;
 }
 
@@ -2273,8 +2286,56 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   // are handed out under call_mutex, held until the event that guards their reuse is recorded, so
   // concurrent calls on one handle (any number of host threads and streams) are safe.
   gik_template *mt = const_cast<gik_template *>(t);
-  std::lock_guard<std::mutex> call_lock(mt->call_mutex);
-  gik_template::CounterSlot &cs = mt->counter_slot[mt->next_counter++ % (unsigned)t->counter_ring];
+  // Hand-out of a slot: the one used last if the launch that used it has completed (hipEventQuery) -- a
+  // sequence of calls then keeps ONE workspace warm instead of growing all of the pool --, else the next one
+  // that no other call holds.  The lock covers the hand-out only: waiting for a slot's previous user, growing
+  // its workspace (hipEventSynchronize / hipFree / hipMalloc) and the launch happen outside it, on a slot
+  // marked in_use.
+  auto take = [&](auto &slots, unsigned &next, unsigned n) -> int {
+    for (;;) {
+      {
+        std::lock_guard<std::mutex> lock(mt->call_mutex);
+        const unsigned last = (next + n - 1) % n;
+        auto &ls = slots[last];
+        if (!ls.in_use && ls.done && (!ls.pending || hipEventQuery(ls.done) == hipSuccess)) {
+          ls.pending = false;
+          ls.in_use = true;
+          return (int)last;
+        }
+        (void)hipGetLastError();      // (hipErrorNotReady of the query)
+        for (unsigned k = 0; k < n; ++k) {
+          const unsigned i = (next + k) % n;
+          if (!slots[i].in_use) {
+            slots[i].in_use = true;
+            next = (i + 1) % n;
+            return (int)i;
+          }
+        }
+      }
+      std::this_thread::yield();      // every slot is between hand-out and launch in some other thread
+    }
+  };
+  auto give_back = [&](auto &slot) {
+    std::lock_guard<std::mutex> lock(mt->call_mutex);
+    slot.pending = true;
+    slot.in_use = false;
+  };
+  gik_template::CounterSlot &cs = mt->counter_slot[take(mt->counter_slot, mt->next_counter, (unsigned)t->counter_ring)];
+  struct Release {      // error paths hand the slots back too (no launch: nothing pending)
+    gik_template *mt;
+    gik_template::CounterSlot *cs;
+    gik_template::SliceWs *sw = nullptr;
+    bool launched = false;
+    ~Release() {
+      std::lock_guard<std::mutex> lock(mt->call_mutex);
+      cs->in_use = false;
+      if (launched) cs->pending = true;
+      if (sw) {
+        sw->in_use = false;
+        if (launched) sw->pending = true;
+      }
+    }
+  } release{mt, &cs};
   a.work_counter = t->d_counters + (&cs - mt->counter_slot.data());
   if (!cs.done && hipEventCreateWithFlags(&cs.done, hipEventDisableTiming) != hipSuccess)
     return fail("hipEventCreate failed");
@@ -2329,12 +2390,17 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     int wslice = (mig && !(a.dbg & 1024)) ? t->wave_slice_its : 0;
     if (wslice > 0 && t->wave_slice_auto && (long long)B > 8LL * grid)
       wslice = (int)std::min<long long>(4LL * wslice, (long long)wslice * B / (8LL * grid));
-    const size_t ycap = wslice > 0 ? (size_t)16 * B + 8192 : 0;
+    // yield queue: a problem yields at most maxiter / slice + 1 times; the margin covers the waves that may be
+    // between the capacity test and their push (mig_anyone_waiting)
+    const size_t ycap = wslice > 0 ? std::min((size_t)B * (size_t)(t->p.maxiter / wslice + 2), (size_t)16 * B + 8192) +
+                                         2 * (size_t)grid + 256
+                                   : 0;      // (very short slices: the queue fills and the problems stop yielding)
     const size_t off_simd = 32, off_seq = off_simd + (mig ? sizeof(int) * MIG_SIMDS : 0), off_ids = off_seq + cap * 4,
                  off_state = (off_ids + cap * 4 + 15) & ~(size_t)15,
                  off_yseq = off_state + (((size_t)B * sizeof(SliceState) + 15) & ~(size_t)15), off_yids = off_yseq + ycap * 4;
     const size_t bytes = off_yids + ycap * 4;
-    sw = &mt->slice_ws[mt->next_slice++ % (unsigned)t->slice_pool];
+    sw = &mt->slice_ws[take(mt->slice_ws, mt->next_slice, (unsigned)t->slice_pool)];
+    release.sw = sw;
     if (!sw->done && hipEventCreateWithFlags(&sw->done, hipEventDisableTiming) != hipSuccess)
       return fail("hipEventCreate failed");
     if (sw->bytes < bytes) {
@@ -2384,12 +2450,9 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
                        dim3(grid), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
   }
   HIP_OK(hipGetLastError());
+  release.launched = true;
   HIP_OK(hipEventRecord(cs.done, (hipStream_t)stream));
-  cs.pending = true;
-  if (sw) {
-    HIP_OK(hipEventRecord(sw->done, (hipStream_t)stream));
-    sw->pending = true;
-  }
+  if (sw) HIP_OK(hipEventRecord(sw->done, (hipStream_t)stream));
   return 0;
 }
 

@@ -86,7 +86,7 @@ def test_bench_self_launches_ranks_and_gathers():
     # ... and the default line (what the driver runs at every N) carries the other BASELINE workloads
     # under "configs": the c4 / c5 tables gathered from two shards equal the one-rank tables
     cf = w2["configs"]
-    assert set(cf) == {"c3", "c4", "c5"}             # (the 8192-goal share line is single-GPU only)
+    assert set(cf) == {"c3", "c4", "c5", "c5_nolimits"}     # (the 8192-goal share line is single-GPU only)
     assert cf["c4"]["rows_sha"] == one["rows_sha"] and cf["c4"]["scaling"] == "strong"
     assert cf["c3"]["rows"] == 2 * 4096 and cf["c3"]["scaling"] == "weak"
     # c5 shards the planar chain the same way (uneven world sizes included)

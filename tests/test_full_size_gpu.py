@@ -381,8 +381,12 @@ def test_rccl_gather_under_torchrun(torch_cuda):
     # BASELINE workload under "configs", all through the same process group
     d = _bench(launcher, "--backend", "nccl")
     assert d["config"]["config"] == "c2" and d["gather"]["backend"] == "nccl" and d["gather"]["rows"] == 4096
-    assert set(d["configs"]) == {"c3", "c4", "c4_share_of_8", "c5"}
-    for name, lo in (("c3", 1000), ("c4", 80e3), ("c4_share_of_8", 35e3), ("c5", 5e6)):
+    assert set(d["configs"]) == {"c3", "c4", "c4_share_of_8", "c5", "c5_nolimits"}
+    assert d["seeds"]["seeds"] == [0, 1, 2, 3] and len(d["seeds"]["ms_per_step"]) == 4
+    assert d["gather"]["bytes_per_problem"] == 8 * (7 + 9) and d["kernels"]["dominant"].startswith("rtr_wave_kernel")
+    assert d["configs"]["c5"]["kernels"]["dominant"] == "prep_wave_kernel" and d["configs"]["c5"]["roofline_prepare"]["frac"] > 0
+    assert d["configs"]["c3"]["kernel"].startswith("rtr_npt_kernel")
+    for name, lo in (("c3", 1300), ("c4", 80e3), ("c4_share_of_8", 35e3), ("c5", 5e6), ("c5_nolimits", 5e6)):
         cf = d["configs"][name]
         assert cf["value"] > lo and 0 < cf["roofline"]["frac_executed"] <= cf["roofline"]["frac"] < 1, (name, cf)
     assert d["configs"]["c3"]["success_rate"] > 0.88 and d["configs"]["c5"]["success_rate"] > 0.999

@@ -524,7 +524,21 @@ def test_drop_in_single_goal(torch_cuda):
     q_sol, Y = solve_with_riemannian(graph, T_goal, use_jit=False)
     assert set(q_sol) == {f"p{i}" for i in range(1, 8)} and Y.shape == (18, 3)
     T_sol = robot.pose(q_sol, "p7")
-    assert np.linalg.norm(T_sol.trans - T_goal.trans) < 5e-3
+    # the same call was captured from the reference (tests/golden/lwa4d.npz, seed 1): same goal, the EE error
+    # within the reference's own band on this goal (3x its 2.1e-4 m / 2.0e-4 rad), and the same IK branch --
+    # joint angles within the self-motion scale of the captured solution (7-DOF: where on the self-motion curve
+    # a solve stops is decided by its start point, and the device's MDS start differs from LAPACK's by the
+    # eigenvector sign rule)
+    from parity_util import wrap_abs
+    d = load_golden("lwa4d")
+    g = int(np.nonzero(d["seed"] == 1)[0][0])
+    assert np.allclose(T_goal.as_matrix(), d["T_goal"][g], atol=1e-12)
+    pos_err = np.linalg.norm(T_sol.trans - T_goal.trans)
+    R_err = T_goal.as_matrix()[:3, :3].T @ T_sol.as_matrix()[:3, :3]
+    rot_err = np.arccos(np.clip((np.trace(R_err) - 1.0) / 2.0, -1.0, 1.0))
+    assert pos_err < 3 * d["pos_err"][g] + 1e-5 and rot_err < 3 * d["rot_err"][g] + 1e-5, (pos_err, rot_err)
+    dq = wrap_abs(robot.q_to_array(q_sol) - d["q_sol"][g]).max()
+    assert dq < 0.2, dq
     q2, _ = solve_with_riemannian(graph, T_goal, jit=False)   # README spelling
     assert q2 is not None
     # RiemannianSolver.solve as the planar example scripts call it
