@@ -544,7 +544,8 @@ class Bench:
         # HBM traffic of the solve kernel from the PMC passes of the SAME workload (tools/profile.sh:
         # rocprofv3 cannot run inside this process), newest round first; null for unprofiled workloads
         tags = {("lwa4d", 4096): ["r04", "r03", "r02"], ("ur10_table", 4096): ["r04_c3"],
-                ("kuka", 65536): ["r03_c4"], ("kuka", 8192): ["r03_c4share"], ("planar10", 65536): ["r03_c5", "r02_c5"]}
+                ("kuka", 65536): ["r04_c4", "r03_c4"], ("kuka", 8192): ["r04_c4share", "r03_c4share"],
+                ("planar10", 65536): ["r04_c5", "r03_c5", "r02_c5"]}
         for tag in ([] if intended else tags.get((robot_name, B), [])):
             traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json" if tag == "r02" else f"{tag}_hbm_traffic.json")
             if not os.path.exists(traffic_file):
