@@ -145,6 +145,7 @@ struct NptCtx {
   double yc[NS][3];
   double L_i00, L_l10, L_l20, L_i11, L_l21, L_i22;
   double ck[4][NE];          // tCG checkpoint (register file)
+  double gq[NS][3];          // clique share of egrad at the point of the last cost() call (see cost())
 #ifdef GIK_NPT_PROF
   long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // developer build: cycles per phase of a product (wavefront 0 of problem 0)
   __device__ inline long long pf_now() const { return (long long)__builtin_readcyclecounter(); }
@@ -511,7 +512,14 @@ struct NptCtx {
         f = fma(c, c, f);
       }
     }
-    if (n_clq) {   // clique pairs, each counted by its lower rank
+    // Clique pairs: the walk of cost() also sums the clique's share of the gradient at this point, c_ij y_ij over
+    // all partners (three multiply-adds more per pair): if the step is accepted, commit() is called for the SAME
+    // point and would repeat the whole walk -- 23 k of the ~50 k cycles an accepted outer iteration costs outside
+    // tCG.  Same pairs, same order, same arithmetic as the separate walk (c^2 == u^2 bit for bit); each pair is
+    // counted in f by its lower rank.
+#pragma unroll
+    for (int s = 0; s < NS; ++s) gq[s][0] = gq[s][1] = gq[s][2] = 0.0;
+    if (n_clq) {
 #pragma unroll 2
       for (int m = 0; m < n_clq; ++m) {
         double r[3];
@@ -521,9 +529,12 @@ struct NptCtx {
         for (int s = 0; s < NS; ++s) {
           const double y0 = x[3 * s] - r[0], y1 = x[3 * s + 1] - r[1], y2 = x[3 * s + 2] - r[2];
           const double d = fma(y2, y2, fma(y1, y1, y0 * y0));
-          const double u = sh_ctg[pair_index(s, m, offm)] - d;
-          const bool mine = inq[s] && m > crank[s];
-          f = fma(mine ? u : 0.0, u, f);
+          const double c = (inq[s] && m != crank[s]) ? d - sh_ctg[pair_index(s, m, offm)] : 0.0;
+          const bool mine = m > crank[s];      // (c == 0 outside the clique)
+          f = fma(mine ? c : 0.0, c, f);
+          gq[s][0] = fma(c, y0, gq[s][0]);
+          gq[s][1] = fma(c, y1, gq[s][1]);
+          gq[s][2] = fma(c, y2, gq[s][2]);
         }
       }
     }
@@ -540,8 +551,8 @@ struct NptCtx {
     }
   }
 
-  // accept the point whose rows are in sh_P (x: the lane's own entries): egrad (lgrad / jgrad,
-  // costs.py:98-123, 19-35) into g, per-term and per-node constants of the Hessian refreshed
+  // accept the point of the LAST cost() call (its rows are in sh_P; x: the lane's own entries): egrad (lgrad /
+  // jgrad, costs.py:98-123, 19-35) into g, per-term and per-node constants of the Hessian refreshed
   __device__ inline void commit(const double (&x)[NE], double (&g)[NE]) {
     double acc[NS][3];
 #pragma unroll
@@ -565,23 +576,12 @@ struct NptCtx {
         put_term(u, t);
       }
     }
-    if (n_clq) {
-#pragma unroll 2
-      for (int m = 0; m < n_clq; ++m) {
-        double r[3];
-        row3(sh_P, (cbase + m) * NPT_RS, r);
-        const int offm = tri_off(m, n_clq);
+    // the clique's share was summed by the cost() call that published this point (commit() always follows the
+    // cost() of the same point: rtr_solve_vec, kat_npt_kernel)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          const double y0 = x[3 * s] - r[0], y1 = x[3 * s + 1] - r[1], y2 = x[3 * s + 2] - r[2];
-          const double d = fma(y2, y2, fma(y1, y1, y0 * y0));
-          const double c = (inq[s] && m != crank[s]) ? d - sh_ctg[pair_index(s, m, offm)] : 0.0;
-          acc[s][0] = fma(c, y0, acc[s][0]);
-          acc[s][1] = fma(c, y1, acc[s][1]);
-          acc[s][2] = fma(c, y2, acc[s][2]);
-        }
-      }
-    }
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[s][q] = gq[s][q];
     if constexpr (NW > 1) {
       if (term_sync) __syncthreads();
     }

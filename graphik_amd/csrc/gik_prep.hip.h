@@ -273,6 +273,7 @@ struct PrepArgs {
   double *dbg_eig;          // [B][3][N]
   int B, sweeps;
   int stop_phase;        // developer build only (GIK_PREP_STOP): leave a goal after phase p (timing)
+  int no_compress;       // workgroup kernel: 1 = full N x N Jacobi even for rank-deficient Gram matrices (tests, A/B)
 };
 
 __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
@@ -763,6 +764,157 @@ __device__ inline int count_eigs_above_blk(double *A, int N, double tau, double 
   return N - below;
 }
 
+// ---- range compression of a rank-deficient symmetric matrix (workgroup-per-goal kernel, N >= 48) ----
+// The Gram matrix of a scene with many anchors has a numerical rank far below N: the anchors' mutual
+// distances are exact, so their block of the distance matrix is a true EDM (rank 5) and the rest is
+// the 2 x (free nodes) rows and columns -- rank ~ 30 at N = 116 (UR10 + table_environment()).  Cyclic
+// Jacobi on the full matrix spends 9 sweeps x 115 rounds x 58 rotations on 86 eigenvalues that are
+// zero to round-off (124 of the kernel's 181 ms per 4096 goals).  Instead: an orthonormal basis Q of
+// range(B) by column-pivoted Gram-Schmidt with re-orthogonalisation (stops when the largest
+// residual column is below 1e-13 |B|_F), M = Q^T B Q (r x r), Jacobi on M, eigenvectors Q W.  The
+// nonzero eigenpairs are those of B to round-off (eps |B|, like LAPACK's); the null space comes out
+// as exact zeros instead of +-1e-16 noise -- generate_initialization() keeps eigenvalues > 1e-8 only
+// (dgp.py:150-171), so nothing downstream sees the difference beyond 1e-8-sized noise columns.
+// Returns the rank r, or -1 if it exceeds PREP_RMAX (A is then restored from the copy and the caller
+// runs the full decomposition).
+constexpr int PREP_COMPRESS_MIN_N = 48;
+constexpr int PREP_RMAX = 64;
+
+// A: N x N (row stride N; LDS or global), destroyed.  Bc: global copy of B (out).  Qt: global, row m =
+// basis vector m (row stride N).  nrm, qv, cj: LDS [PREP_MAXN] each.
+__device__ inline int range_basis_blk(double *A, int N, double *Bc, double *Qt, double *nrm, double *qv, double *cj,
+                                      double *red, int tid) {
+  const int NN = N * N;
+  for (int e = tid; e < NN; e += PREP_NT) Bc[e] = A[e];
+  if (tid < N) {
+    double s = 0.0;
+    for (int i = 0; i < N; ++i) s = fma(A[i * N + tid], A[i * N + tid], s);
+    nrm[tid] = s;
+  }
+  __syncthreads();
+  double fro2 = 0.0;
+  for (int j = 0; j < N; ++j) fro2 += nrm[j];
+  const double tol2 = 1e-26 * fro2;
+  const int e_i0 = tid / N, e_j0 = tid - e_i0 * N, e_dq = PREP_NT / N, e_dr = PREP_NT - e_dq * N;   // element stepping
+  int r = 0;
+  for (;;) {
+    double best = -1.0;
+    int p = 0;
+    for (int j = 0; j < N; ++j) {
+      const double v = nrm[j];
+      if (v > best) {
+        best = v;
+        p = j;
+      }
+    }
+    if (!(best > tol2)) break;
+    if (r >= PREP_RMAX) {      // not a low-rank matrix: hand the original back
+      __syncthreads();
+      for (int e = tid; e < NN; e += PREP_NT) A[e] = Bc[e];
+      __syncthreads();
+      return -1;
+    }
+    // candidate: the residual column, re-orthogonalised twice against the basis so far (the deflated column
+    // is orthogonal to it up to eps x the growth of the pivots, 1e11 here)
+    double qi = tid < N ? A[tid * N + p] : 0.0;
+    for (int pass = 0; pass < 2 && r > 0; ++pass) {
+      if (tid < N) qv[tid] = qi;
+      __syncthreads();
+      {   // d_m = <q_m, q>: eight threads per basis vector
+        const int m = tid >> 3, part = tid & 7;
+        double d = 0.0;
+        if (m < r)
+          for (int i = part; i < N; i += 8) d = fma(Qt[m * N + i], qv[i], d);
+        d += dpp_f64<0xB1>(d);
+        d += dpp_f64<0x4E>(d);
+        d += dpp_f64<0x141>(d);   // row_half_mirror: lanes 0..7 of a group of 8
+        if (part == 0 && m < PREP_RMAX) cj[m] = m < r ? d : 0.0;
+      }
+      __syncthreads();
+      if (tid < N)
+        for (int m = 0; m < r; ++m) qi = fma(-cj[m], Qt[m * N + tid], qi);
+      __syncthreads();
+    }
+    const double nn = prep_block_sum(qi * qi, red, tid);
+    if (!(nn > tol2)) {        // numerically dependent on the basis: drop the column
+      if (tid == 0) nrm[p] = 0.0;
+      __syncthreads();
+      continue;
+    }
+    qi *= 1.0 / sqrt(nn);
+    if (tid < N) {
+      qv[tid] = qi;
+      Qt[r * N + tid] = qi;
+    }
+    __syncthreads();
+    {   // c_j = <q, A[:, j]>: four threads per column
+      const int j = tid >> 2, part = tid & 3;
+      double c = 0.0;
+      if (j < N)
+        for (int i = part; i < N; i += 4) c = fma(qv[i], A[i * N + j], c);
+      c += dpp_f64<0xB1>(c);
+      c += dpp_f64<0x4E>(c);
+      if (part == 0 && j < N) cj[j] = c;
+    }
+    __syncthreads();
+    {   // deflate: A -= q c^T
+      int i = e_i0, j = e_j0;
+      for (int e = tid; e < NN; e += PREP_NT) {
+        A[i * N + j] = fma(-qv[i], cj[j], A[i * N + j]);
+        i += e_dq;
+        j += e_dr;
+        if (j >= N) {
+          j -= N;
+          ++i;
+        }
+      }
+    }
+    if (tid < N) nrm[tid] = tid == p ? 0.0 : fmax(fma(-cj[tid], cj[tid], nrm[tid]), 0.0);
+    ++r;
+    __syncthreads();
+  }
+  return r;
+}
+
+// B (global copy Bc) in the basis Qt: Tt[l] = B q_l (global, row stride N), M = Q^T B Q symmetrised into the
+// leading r x r block of A (row stride N), W = identity (global, row stride N).
+__device__ inline void compress_to_basis_blk(double *A, int N, int r, const double *Bc, const double *Qt, double *Tt,
+                                             double *W, int tid) {
+  for (int e = tid; e < r * N; e += PREP_NT) {      // e = l * N + i
+    const int l = e / N, i = e - l * N;
+    double s = 0.0;
+    for (int j = 0; j < N; ++j) s = fma(Bc[i * N + j], Qt[l * N + j], s);
+    Tt[e] = s;
+  }
+  __syncthreads();
+  for (int e = tid; e < r * r; e += PREP_NT) {
+    const int k = e / r, l = e - k * r;
+    double s = 0.0, t = 0.0;
+    for (int i = 0; i < N; ++i) {
+      s = fma(Qt[k * N + i], Tt[l * N + i], s);
+      t = fma(Qt[l * N + i], Tt[k * N + i], t);
+    }
+    A[k * N + l] = 0.5 * (s + t);
+    W[k * N + l] = k == l ? 1.0 : 0.0;
+  }
+  __syncthreads();
+}
+
+// eigenvectors of B from those of M: V[i][k] = sum_m Q[i][m] W[m][k] (k < r), zero columns beyond; the
+// eigenvalues stay on A's diagonal (zeros beyond r)
+__device__ inline void expand_from_basis_blk(double *A, double *V, int N, int r, const double *Qt, const double *W,
+                                             int tid) {
+  for (int e = tid; e < N * N; e += PREP_NT) {      // e = k * N + i: consecutive threads take consecutive rows i
+    const int k = e / N, i = e - k * N;
+    double s = 0.0;
+    if (k < r)
+      for (int m = 0; m < r; ++m) s = fma(Qt[m * N + i], W[m * N + k], s);
+    V[i * N + k] = s;
+  }
+  if (tid >= r && tid < N) A[tid * N + tid] = 0.0;
+  __syncthreads();
+}
+
 // A_LDS: the matrix being worked on (the upper bounds during the N Floyd-Warshall rounds, then the
 // Gram matrix = Jacobi / Householder work matrix, then the scatter matrix) lives in the dynamic LDS
 // segment instead of the global slab -- the kernel is bound by the L2 traffic of the Jacobi rounds,
@@ -874,7 +1026,23 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
 #ifdef GIK_DEV
     if (a.stop_phase == 4) continue;
 #endif
-    jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid, -1, dl);
+    {
+      int rnk = -1;
+      if (A_LDS && N >= PREP_COMPRESS_MIN_N && !a.no_compress) {
+        // (global buffers free at this point: the slab's copy of the upper bounds Ug -- they live in LDS --, the
+        // lower bounds L, the max-plus intermediate A1, X; graphs whose work matrix itself sits in the slab,
+        // N > 123, keep the full decomposition)
+        double *Bc = A1, *Qt = X, *Tt = L, *W = Ug;
+        rnk = range_basis_blk(A, N, Bc, Qt, ev, sg, cs, red, tid);
+        if (rnk >= 0) {
+          compress_to_basis_blk(A, N, rnk, Bc, Qt, Tt, W, tid);
+          if (rnk > 1) jacobi_blk(A, W, N, a.sweeps, cs, pq, red, tid, rnk, dl);
+          __syncthreads();
+          expand_from_basis_blk(A, V, N, rnk, Qt, W, tid);
+        }
+      }
+      if (rnk < 0) jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid, -1, dl);
+    }
 #ifdef GIK_DEV
     if (a.stop_phase == 5) continue;
 #endif

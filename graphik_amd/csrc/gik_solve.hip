@@ -1177,6 +1177,7 @@ struct gik_template {
   int prep_waves_per_cu = 8;   // resident prepare waves (workgroups on the block variant) per CU
   bool prep_block = false;
   bool prep_a_lds = false;     // block variant: work matrix in LDS
+  bool prep_no_compress = false;   // block variant: full N x N Jacobi even where the Gram matrix is rank deficient
   double *prep_ws = nullptr;   // [n_cu * prep_waves_per_cu][5][N*N] (block variant)
   hipEvent_t prep_done = nullptr;   // block variant: launches share prep_ws, so each one waits
   std::mutex prep_mutex;            // for the previous one (whatever stream it ran on)
@@ -1972,6 +1973,7 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   // graphs beyond one wavefront's LDS: workgroup-per-goal kernel with its matrices in a global slab
   t->prep_block = N > 32 || d->n_anchor > 32 || d->force_block_prepare != 0 ||
                   getenv("GIK_PREP_FORCE_BLOCK") != nullptr;
+  t->prep_no_compress = getenv("GIK_PREP_NO_COMPRESS") != nullptr;   // (developer A/B switch, read once, here)
   if (t->prep_block) {
     int occ = 0;
     // work matrix in LDS when it fits next to the kernel's static arrays (N <= 123), one workgroup per CU
@@ -2037,6 +2039,7 @@ int gik_prepare_batch_debug(const gik_template *t, const double *d_T_goal, int B
   a.B = B;
   a.sweeps = t->sweeps;
   a.stop_phase = 0;
+  a.no_compress = t->prep_no_compress ? 1 : 0;
 #ifdef GIK_DEV
   if (const char *e = getenv("GIK_PREP_STOP")) a.stop_phase = atoi(e);   // developer build: timing of the phases
 #endif
