@@ -1,0 +1,219 @@
+// graphik_amd/csrc/gik_quad.hip.h -- four planar IK problems per wavefront (gfx950 / CDNA4)
+//
+// A planar problem is small: at most 16 nodes with two coordinates each (the 10-link chain of
+// BASELINE configs[4]: N = 13).  Run one per wavefront (gik_wave.hip.h) it leaves 38 of the 64 lanes
+// idle and -- worse -- every per-problem SCALAR of the trust-region solver (alpha, beta, tau, the
+// literal 4 x 4 solve of the k = 2 projector, the acceptance test ...) is one wave-wide instruction
+// for one number: measured, round 4, 19 k VALU instructions per problem of which the vectors need a
+// fraction.  Here a wavefront holds FOUR problems:
+//
+//   lane l = 16 r + 4 b + i   ->   problem slot b (0..3), node n = 4 r + i (0..15)
+//
+// i.e. a problem is one 4-lane block column of the wave's four rows.  That is the set of lanes
+// v_mfma_f64_4x4x4 sums over (see wave_sum_n in gik_wave.hip.h): two MFMAs leave every lane with the
+// total over its problem's 16 lanes, bit-identical in all of them, so
+//   * a lane owns a whole NODE (both coordinates of every tangent vector in registers): the Hessian
+//     product needs one 16-byte row gather per neighbour and no exchange between lanes,
+//   * every solver scalar is an ordinary per-lane value, equal in the 16 lanes of its problem: one
+//     instruction stream serves four problems, and
+//   * the problems need not be in step: each slot carries its own state, truncated CG runs until the
+//     slowest of the four has left it, and a slot whose problem met a stopping rule claims the next
+//     one from the batch queue at once (its first cost / gradient evaluation is the same code a
+//     continuing problem runs for its proposal).
+// Arithmetic per problem is trust_region.py's, term by term as in rtr_solve_one's k = 2 branch; the
+// inner products are summed in a different order (per node first, then over the nodes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gik_rtr.hip.h"
+
+namespace gik {
+
+constexpr int QUAD_SLOTS = 4;    // problems per wavefront
+constexpr int QUAD_NODES = 16;   // nodes per problem
+
+// total over the 16 lanes of this lane's problem slot, identical in all of them
+__device__ inline double quad_sum(double v) { return mfma_blocksum(v); }
+__device__ inline bool quad_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+
+template <int DEG>
+struct QuadCtx {
+  int lane, slot, node;
+  bool has_node;
+  double2 *sh_P;     // [4][16] rows of the point last given to cost()
+  double2 *sh_W;     // [4][16] rows of the direction given to ehess()
+  int own;           // this lane's row
+  // slot s: [9:0] byte offset of the neighbour's row (own row: padding), [10] the residual has no lower
+  // clamp, [11] no upper clamp (residual = clamp(target - d, lo, hi) with lo = -inf / 0, hi = +inf / 0: EQ (-inf, +inf),
+  // LOWER (0, +inf), UPPER (-inf, 0), padding (0, 0) -- see WaveCtx::SlotRec), [31:16] term index
+  uint32_t sl[DEG];
+  double tg[DEG];    // per problem: squared target distances
+  // per committed point: ys = 2 a (Y_i - Y_j) (a = 1 where the term is active, else 0), cc = 2 c
+  double ys0[DEG], ys1[DEG], cc[DEG];
+  double pk[2], pk2[2], G2;   // k = 2 projector (fixed_rank_psd_sym.py:107-113; Pm = 1)
+
+  __host__ __device__ static constexpr size_t lds_bytes() {
+    return 2 * sizeof(double2) * QUAD_SLOTS * QUAD_NODES + sizeof(int) * 2 * QUAD_SLOTS;
+  }
+
+  // g_meta: the wavefront kernel's slot table [DEG][64] (lane = 2 node + component)
+  __device__ inline void init(int lane_, int N, double2 *P, double2 *W, const uint32_t *g_meta) {
+    lane = lane_;
+    slot = (lane >> 2) & 3;
+    node = ((lane >> 4) << 2) | (lane & 3);
+    has_node = node < N;
+    sh_P = P;
+    sh_W = W;
+    own = slot * QUAD_NODES + node;
+#pragma unroll
+    for (int s = 0; s < DEG; ++s) {
+      // (a padding slot of the table names the node itself with kind 0: residual clamp(., 0, 0) = 0)
+      const uint32_t m = has_node ? g_meta[s * WAVE + 2 * node] : meta_pack(node, 0, 0, 0);
+      const int kind = meta_kind(m);
+      sl[s] = (uint32_t)((slot * QUAD_NODES + meta_j(m)) * sizeof(double2)) |
+              ((kind == GIK_TERM_EQ || kind == GIK_TERM_UPPER) ? 0x400u : 0u) |
+              ((kind == GIK_TERM_EQ || kind == GIK_TERM_LOWER) ? 0x800u : 0u) | ((uint32_t)meta_term(m) << 16);
+      tg[s] = 0.0;
+      ys0[s] = ys1[s] = cc[s] = 0.0;
+    }
+    pk[0] = pk[1] = pk2[0] = pk2[1] = G2 = 0.0;
+    sh_P[lane] = make_double2(0.0, 0.0);
+    sh_W[lane] = make_double2(0.0, 0.0);
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // per problem (divergent: only the lanes of the slot that starts problem b)
+  __device__ inline void load_targets(const double *targets_b) {
+#pragma unroll
+    for (int s = 0; s < DEG; ++s) tg[s] = targets_b[sl[s] >> 16];
+  }
+  __device__ inline const double2 &row(const double2 *base, int s) const {
+    return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + (sl[s] & 0x3ffu));
+  }
+  // clamp(u, lo, hi) of slot s (the bounds differ from 0 in their upper word only)
+  __device__ inline double residual(int s, double u) const {
+    const double lo = __hiloint2double((sl[s] & 0x400u) ? (int)0xfff00000 : 0, 0);
+    const double hi = __hiloint2double((sl[s] & 0x800u) ? 0x7ff00000 : 0, 0);
+    return fmin(fmax(u, lo), hi);
+  }
+
+  // f(x): lcost / jcost (costs.py:80-93, 8-16); leaves the rows of x in sh_P.  Every term sits in
+  // the slot lists of both of its nodes, so each is counted twice and the total is halved (exact).
+  // Wave-uniform call; slots without a problem compute on whatever they hold.
+  __device__ inline double cost(double x0, double x1) {
+    __builtin_amdgcn_wave_barrier();
+    sh_P[own] = make_double2(x0, x1);
+    __builtin_amdgcn_wave_barrier();
+    double f = 0.0;
+#pragma unroll
+    for (int s = 0; s < DEG; ++s) {
+      const double2 r = row(sh_P, s);
+      const double a = x0 - r.x, b = x1 - r.y;
+      const double d = fma(b, b, a * a);
+      const double cl = residual(s, tg[s] - d);
+      f = fma(cl, cl, f);
+    }
+    return 0.5 * quad_sum(has_node ? f : 0.0);
+  }
+
+  // egrad at the point whose rows are in sh_P (lgrad / jgrad, costs.py:98-123, 20-35) and the
+  // per-slot constants of the Hessian there.  No cross-lane step: may be called by some slots only.
+  __device__ inline void commit(double &g0, double &g1) {
+    const double2 o = sh_P[own];
+    double G0 = 0.0, G1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < DEG; ++s) {
+      const double2 r = row(sh_P, s);
+      const double a = o.x - r.x, b = o.y - r.y;
+      const double d = fma(b, b, a * a);
+      const double cl = residual(s, tg[s] - d);
+      // active: an equality always, a hinge iff its clamped residual is non-zero
+      const bool act = ((sl[s] & 0xc00u) == 0xc00u) || (cl != 0.0);
+      const double c = -cl;
+      ys0[s] = act ? a + a : 0.0;
+      ys1[s] = act ? b + b : 0.0;
+      cc[s] = c + c;
+      G0 = fma(c, a, G0);
+      G1 = fma(c, b, G1);
+    }
+    g0 = G0 + G0;
+    g1 = G1 + G1;
+  }
+
+  // ehess(Y, W) (lhess / jhess, costs.py:175-207, 39-58) at the last commit():
+  //   H_i = sum_j [ 4 a (y.w) y + 2 c w ],  y = Y_i - Y_j,  w = W_i - W_j     (4 a y y^T = ys ys^T)
+  __device__ inline void ehess(double w0, double w1, double &h0, double &h1) {
+    __builtin_amdgcn_wave_barrier();
+    sh_W[own] = make_double2(w0, w1);
+    __builtin_amdgcn_wave_barrier();
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < DEG; ++s) {
+      const double2 r = row(sh_W, s);
+      const double u0 = w0 - r.x, u1 = w1 - r.y;
+      const double t = fma(ys1[s], u1, ys0[s] * u0);
+      a0 = fma(t, ys0[s], fma(cc[s], u0, a0));
+      a1 = fma(t, ys1[s], fma(cc[s], u1, a1));
+    }
+    h0 = a0;
+    h1 = a1;
+  }
+
+  // Horizontal-space projector at x (PSDFixedRank.proj, fixed_rank_psd_sym.py:91-113), k = 2: the
+  // literal 4 x 4 matrix of :107-110 solved for the right-hand side [0, 1, -1, 0] (see
+  // WaveCtx::proj_setup).  A function of x alone: slots whose point did not change get the same
+  // values again, bit for bit.
+  __device__ inline void proj_setup(double x0, double x1, int planar_proj_exact) {
+    const double hm = has_node ? 1.0 : 0.0;
+    const double X00 = quad_sum(hm * x0 * x0), X01 = quad_sum(hm * x0 * x1), X11 = quad_sum(hm * x1 * x1);
+    double u0, u1, u2, u3;
+    if (planar_proj_exact) {
+      const double it = 1.0 / (X00 + X11);
+      u0 = 0.0; u1 = it; u2 = -it; u3 = 0.0;
+    } else {
+      double A[4][5] = {{X00 + X00, X01, X01, 0.0, 0.0},
+                        {X01, X01 + X00, 0.0, X01, 1.0},
+                        {X01, 0.0, X00 + X11, X01, -1.0},
+                        {0.0, X01, X01, X11 + X11, 0.0}};
+#pragma unroll
+      for (int col = 0; col < 4; ++col) {
+#pragma unroll
+        for (int r = col + 1; r < 4; ++r) {  // partial pivoting by compare-and-swap
+          const bool sw = fabs(A[r][col]) > fabs(A[col][col]);
+#pragma unroll
+          for (int t = 0; t < 5; ++t) {
+            const double p = A[col][t], q = A[r][t];
+            A[col][t] = sw ? q : p;
+            A[r][t] = sw ? p : q;
+          }
+        }
+        const double ip = 1.0 / A[col][col];
+#pragma unroll
+        for (int r = col + 1; r < 4; ++r) {
+          const double fct = A[r][col] * ip;
+#pragma unroll
+          for (int t = col; t < 5; ++t) A[r][t] = fma(-fct, A[col][t], A[r][t]);
+        }
+      }
+      u3 = A[3][4] / A[3][3];
+      u2 = (A[2][4] - A[2][3] * u3) / A[2][2];
+      u1 = (A[1][4] - A[1][2] * u2 - A[1][3] * u3) / A[1][1];
+      u0 = (A[0][4] - A[0][1] * u1 - A[0][2] * u2 - A[0][3] * u3) / A[0][0];
+    }
+    pk[0] = -hm * x1;
+    pk[1] = hm * x0;
+    pk2[0] = hm * (x0 * u0 + x1 * u2);
+    pk2[1] = hm * (x0 * u1 + x1 * u3);
+    G2 = quad_sum(fma(pk2[1], pk2[1], pk2[0] * pk2[0]));
+  }
+};
+
+// what a slot hands back when its problem meets a stopping rule
+struct QuadStats {
+  double f, gradnorm, Delta;
+  int iterations, inner_total, stop, n_accept;
+};
+
+}  // namespace gik

@@ -20,6 +20,7 @@
 
 #include "gik_block.hip.h"
 #include "gik_npt.hip.h"
+#include "gik_quad.hip.h"
 #include "gik_prep.hip.h"
 #include "gik_rcg.hip.h"
 #include "gik_rtr.hip.h"
@@ -853,6 +854,237 @@ static const NptVariant kNptVariants[] = {GIK_NPT_VARIANT(1, 1, 2), GIK_NPT_VARI
                                           GIK_NPT_VARIANT(4, 2, 1)};
 
 // ------------------------------------------------------------------------------------------
+// Four planar problems per wavefront (gik_quad.hip.h): TrustRegions.solve (trust_region.py:112-434)
+// with _truncated_conjugate_gradient (:436-599), the k = 2 branch of rtr_solve_one with every
+// solver scalar a per-lane value and every decision a lane mask.  One pass of the outer loop below is
+//   refill : slots without a problem claim the next one of the batch (fresh: x = Y_init, no step yet)
+//   tCG    : the slots that continue a problem run truncated CG together until the last has left it
+//   step   : cost of the proposal x + eta (fresh: of x itself), the acceptance test (:248-382; a
+//            fresh problem "accepts" its start point), gradient / Hessian constants / projector at
+//            the accepted points, stopping rules (:414-416), results of the finished slots.
+template <int DEG>
+__global__ void __launch_bounds__(WAVE, 2) rtr_quad_kernel(SolveArgs a) {
+  using Ctx = QuadCtx<DEG>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  double2 *sh_P = reinterpret_cast<double2 *>(smem);
+  double2 *sh_W = sh_P + QUAD_SLOTS * QUAD_NODES;
+  int *sh_claim = reinterpret_cast<int *>(sh_W + QUAD_SLOTS * QUAD_NODES);
+  Ctx cx;
+  cx.init(lane, a.N, sh_P, sh_W, a.slot_meta);
+  const Params &p = a.p;
+  const int NK = a.N * 2;
+  const bool lead = cx.node == 0;
+  const double Delta_bar = 10.0 + 2;            // typicaldist (fixed_rank_psd_sym.py:71-73), k = 2
+  const double hm = cx.has_node ? 1.0 : 0.0;
+
+  // per-slot state (equal in the 16 lanes of a slot)
+  bool alive = false, fresh = false, more = true;
+  int b = -1, kiter = 0, inner_total = 0, n_accept = 0;
+  double x0 = 0.0, x1 = 0.0, g0 = 0.0, g1 = 0.0, fx = 0.0, Delta = 0.0, norm_grad = 0.0, rho0 = 0.0;
+
+  for (;;) {
+    // ---------------- refill ----------------
+    const bool want = !alive && more;
+    if (quad_any(want)) {
+      if (want && lead) {
+        const unsigned int t = atomicAdd(a.work_counter, 1u);
+        sh_claim[cx.slot] = t < (unsigned)a.B ? (int)t : -1;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (want) {
+        const int nb = sh_claim[cx.slot];
+        if (nb >= 0) {
+          b = nb;
+          alive = fresh = true;
+          cx.load_targets(a.targets + (size_t)b * a.T);
+          const double2 xi = cx.has_node ? *reinterpret_cast<const double2 *>(a.Y_init + (size_t)b * NK + 2 * cx.node)
+                                         : make_double2(0.0, 0.0);
+          x0 = xi.x;
+          x1 = xi.y;
+          kiter = inner_total = n_accept = 0;
+          Delta = Delta_bar / 8.0;                   // trust_region.py:134-135,164
+        } else {
+          more = false;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (!quad_any(alive)) break;
+
+    // ---------------- _truncated_conjugate_gradient (:436-599) ----------------
+    const bool run = alive && !fresh;
+    double eta0 = 0.0, eta1 = 0.0, He0 = 0.0, He1 = 0.0;     // :444-445
+    int stop_tCG = TCG_MAX_INNER_ITER;                       // :491
+    int jx = p.maxinner - 1;                                 // Python leaves j at the last index
+    bool bad = false;
+    const double Delta2 = Delta * Delta;
+    if (quad_any(run)) {
+      double r0 = g0, r1 = g1;                               // :448
+      double e_Pe = 0.0;
+      double r_r = quad_sum(fma(r1, r1, r0 * r0));           // :455
+      const double norm_r0 = sqrt(r_r);
+      const double target = norm_r0 * fmin(norm_r0, p.kappa);   // rhs of :572 (theta = 1)
+      const double target2 = target * target;
+      const int stop_target = (p.kappa < norm_r0) ? TCG_REACHED_TARGET_LINEAR : TCG_REACHED_TARGET_SUPERLINEAR;
+      double z_r = r_r, d_Pd = r_r;                          // :464-466 (precon = identity)
+      double inv_z_r = frcp(z_r);
+      double d0 = -r0, d1 = -r1;                             // :469
+      double e_Pd = 0.0, model_value = 0.0;                  // :471,485
+      double rho_pk = rho0, s_pk = -rho0;                    // <r, pk2>, <delta, pk2>
+      bool act = run && p.maxinner > 0;
+      int j = 0;
+      while (quad_any(act)) {                                // :495
+        double H0, H1;
+        cx.ehess(d0, d1, H0, H1);                            // :497
+        const double v0 = quad_sum(fma(cx.pk[1], H1, cx.pk[0] * H0));
+        const double v1 = quad_sum(fma(d1, H1, d0 * H0));
+        const double v2 = quad_sum(fma(cx.pk2[1], H1, cx.pk2[0] * H0));
+        // rhess = proj(ehess) (:497-500): Omega = v0 (Pm = 1), see WaveCtx::proj_dot
+        const double Hd0 = fma(-cx.pk2[0], v0, H0), Hd1 = fma(-cx.pk2[1], v0, H1);
+        const double d_Hd = fma(-v0, s_pk, v1);              // :500
+        const double hd_pk = fma(-v0, cx.G2, v2);
+        const bool nan = act && !(d_Hd == d_Hd);
+        bad = bad || nan;
+        act = act && !nan;
+        const double alpha = z_r * frcp(d_Hd);               // :503
+        const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;   // :506
+        const bool exb = act && (d_Hd <= 0.0 || e_Pe_new >= Delta2);                // :509
+        if (exb) {
+          const double tau = (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta2 - e_Pe))) / d_Pd;   // :514
+          eta0 = eta0 + tau * d0;                            // :516
+          eta1 = eta1 + tau * d1;
+          He0 = He0 + tau * Hd0;                             // :521
+          He1 = He1 + tau * Hd1;
+          stop_tCG = (d_Hd <= 0.0) ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;      // :531-534
+          jx = j;
+        }
+        act = act && !exb;
+        if (!quad_any(act)) break;
+        const double ne0 = eta0 + alpha * d0, ne1 = eta1 + alpha * d1;              // :538
+        const double nH0 = He0 + alpha * Hd0, nH1 = He1 + alpha * Hd1;              // :542
+        const double nr0 = r0 + alpha * Hd0, nr1 = r1 + alpha * Hd1;                // :561
+        const double m0 = quad_sum(fma(ne1, g1, ne0 * g0));
+        const double m1 = quad_sum(fma(ne1, nH1, ne0 * nH0));
+        const double m2 = quad_sum(fma(nr1, nr1, nr0 * nr0));
+        const double new_model_value = m0 + 0.5 * m1;        // :551
+        const bool exm = act && (new_model_value >= model_value);                   // :552
+        if (exm) {
+          stop_tCG = TCG_MODEL_INCREASED;
+          jx = j;
+        }
+        act = act && !exm;
+        if (act) {
+          e_Pe = e_Pe_new;                                   // :537
+          eta0 = ne0;                                        // :556-558
+          eta1 = ne1;
+          He0 = nH0;
+          He1 = nH1;
+          model_value = new_model_value;
+          r0 = nr0;                                          // :561
+          r1 = nr1;
+          r_r = m2;                                          // :564
+        }
+        const bool ext = act && (j >= p.mininner && r_r <= target2);                // :572
+        if (ext) {
+          stop_tCG = stop_target;
+          jx = j;
+        }
+        act = act && !ext;
+        act = act && (j + 1 < p.maxinner);                   // :495 exhausted: stop stays MAX_INNER_ITER
+        if (act) {
+          z_r = r_r;                                         // :589
+          const double beta = z_r * inv_z_r;                 // :592
+          inv_z_r = frcp(z_r);
+          d0 = -r0 + beta * d0;                              // :593
+          d1 = -r1 + beta * d1;
+          rho_pk = fma(alpha, hd_pk, rho_pk);
+          s_pk = fma(beta, s_pk, -rho_pk);
+          e_Pd = beta * (e_Pd + alpha * d_Pd);               // :596
+          d_Pd = z_r + beta * beta * d_Pd;                   // :597
+        }
+        ++j;
+      }
+    }
+    // (a NaN in tCG leaves the solve as rtr_solve_one does: point, counters and statistics as before it)
+    const bool step = run && !bad;
+    if (step) inner_total += jx + 1;
+
+    // ---------------- outer iteration (:248-422) ----------------
+    const bool tr = a.has_trace && step && lead && kiter < a.trace.cap;
+    if (tr) {
+      const size_t q = (size_t)b * a.trace.cap + kiter;
+      a.trace.d_Delta[q] = Delta;
+      a.trace.d_numit[q] = jx;
+      a.trace.d_stop[q] = stop_tCG;
+      a.trace.d_f_before[q] = fx;
+    }
+    const double xp0 = fresh ? x0 : x0 + eta0, xp1 = fresh ? x1 : x1 + eta1;        // :248 retr
+    const double fx_prop = cx.cost(xp0, xp1);                // :251 (fresh: :159)
+    const double gd0 = quad_sum(fma(g1, eta1, g0 * eta0)), gd1 = quad_sum(fma(eta1, He1, eta0 * He0));
+    double rhonum = fx - fx_prop;                            // :255
+    double rhoden = -gd0 - 0.5 * gd1;                        // :256
+    const double rho_reg = fmax(1.0, fabs(fx)) * 2.220446049250313e-16 * p.rho_regularization;   // :287
+    rhonum += rho_reg;                                       // :288
+    rhoden += rho_reg;                                       // :289
+    const bool model_decreased = rhoden >= 0.0;              // :311
+    const double rho = rhonum / rhoden;                      // :317
+    if (step) {
+      if (rho < 0.25 || !model_decreased || !(rho == rho)) {                        // :336
+        Delta = Delta / 4.0;                                 // :338
+      } else if (rho > 0.75 && (stop_tCG == TCG_NEGATIVE_CURVATURE || stop_tCG == TCG_EXCEEDED_TR)) {
+        Delta = fmin(2.0 * Delta, Delta_bar);                // :357-361
+      }
+    }
+    const bool accept = step && model_decreased && rho > p.rho_prime;               // :382
+    if (accept || fresh) {
+      x0 = xp0;                                              // :385
+      x1 = xp1;
+      fx = fx_prop;                                          // :386
+      cx.commit(g0, g1);                                     // :387 (fresh: :160)
+    }
+    if (accept) ++n_accept;
+    // projector, ||grad|| and <grad, pk2> are functions of (x, grad): recomputed for every slot, the
+    // same bits again where nothing was accepted
+    cx.proj_setup(x0, x1, p.planar_proj_exact);
+    norm_grad = sqrt(quad_sum(hm * fma(g1, g1, g0 * g0)));   // :388 (fresh: :161)
+    rho0 = quad_sum(fma(g1, cx.pk2[1], g0 * cx.pk2[0]));
+    if (tr) {
+      const size_t q = (size_t)b * a.trace.cap + kiter;
+      a.trace.d_gradnorm_after[q] = norm_grad;
+      a.trace.d_accept[q] = accept ? 1 : 0;
+    }
+    if (step) ++kiter;                                       // :394
+    // :414-416 stopping criterion (pymanopt 0.2.5 order: maxiter before gradnorm)
+    const bool isnan = !(norm_grad == norm_grad) || !(fx == fx);
+    int stop = -1;
+    if (bad) stop = 2;
+    else if (step && kiter >= p.maxiter) stop = 1;
+    else if (step && norm_grad < p.mingradnorm) stop = 0;
+    else if (alive && (isnan || (a.dbg & 2))) stop = 2;
+    const bool fin = alive && stop >= 0;
+    if (fin) {
+      if (cx.has_node) *reinterpret_cast<double2 *>(a.Y_out + (size_t)b * NK + 2 * cx.node) = make_double2(x0, x1);
+      if (lead) {
+        gik_stats s;
+        s.f = fx;
+        s.gradnorm = norm_grad;
+        s.iterations = kiter;
+        s.inner_total = inner_total;
+        s.stop = stop;
+        s.n_accept = n_accept;
+        s.inner_executed = inner_total;
+        s.flags = 0;
+        s.stepsize = Delta;
+        a.stats[b] = s;
+      }
+      alive = false;
+    }
+    fresh = false;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // developer micro-benchmark: per-component cycle cost of one wavefront.  Only in the -DGIK_DEV
 // build (graphik_amd/build.py --dev -> lib/exp/libgraphik_amd_dev.so); the shipped library has
 // neither this kernel nor the gik_debug_* hooks.
@@ -1169,6 +1401,11 @@ struct gik_template {
   const gik::NptVariant *npt_variant = nullptr;
   size_t npt_smem = 0;
   int npt_waves_per_cu = 1;
+  // four-problems-per-wavefront path (rtr_quad_kernel): trust-region solves of planar graphs with at most
+  // 16 nodes and 6 terms per node; everything else of such a template stays on the wavefront kernels
+  void (*quad_solve)(gik::SolveArgs) = nullptr;
+  size_t quad_smem = 0;
+  int quad_waves_per_cu = 8;
   // device pre/post-processing (gik_pipeline_attach)
   bool has_pipe;
   gik::PipeConst pc;
@@ -1751,6 +1988,14 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   }
   t->n_cu = prop.multiProcessorCount;
   t->waves_per_cu = std::max(1, std::min(occ, 32));
+  if (!is_block && !ad && !cg && d->k == 2 && N <= QUAD_NODES && var->maxdeg == 6 && d->theta == 1.0 &&
+      !(d->debug_flags & 8192) && !getenv("GIK_NO_QUAD")) {
+    t->quad_solve = rtr_quad_kernel<6>;
+    t->quad_smem = QuadCtx<6>::lds_bytes();
+    int qocc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&qocc, (const void *)t->quad_solve, WAVE, t->quad_smem) == hipSuccess)
+      t->quad_waves_per_cu = std::max(1, std::min(qocc, 32));
+  }
   if (ad) {
     // ---- fixed-anchor data ----
     bool ok = true;
@@ -2437,7 +2682,14 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     if (mig || t->is_npt) HIP_OK(hipMemsetAsync(a.q_state, 0, (size_t)B * sizeof(SliceState), (hipStream_t)stream));
     if (ycap) HIP_OK(hipMemsetAsync(a.y_seq, 0, ycap * 4, (hipStream_t)stream));
   }
-  if (t->is_npt) {
+  const bool quad = t->quad_solve && !(a.dbg & (1 | 8192));
+  if (quad) {
+    // a wavefront holds four problems: a quarter of the waves (at least one slot each), no slicing
+    int qw = t->quad_waves_per_cu;
+    if (t->wpc_override > 0) qw = t->wpc_override;
+    const int qgrid = std::max(1, std::min((B + QUAD_SLOTS - 1) / QUAD_SLOTS, t->n_cu * qw));
+    hipLaunchKernelGGL(t->quad_solve, dim3(qgrid), dim3(WAVE), t->quad_smem, (hipStream_t)stream, a);
+  } else if (t->is_npt) {
     a.nt = t->nt;
     hipLaunchKernelGGL(t->npt_variant->solve, dim3(grid), dim3(WAVE * t->npt_variant->NW), t->npt_smem, (hipStream_t)stream, a);
   } else if (t->is_block) {
@@ -2475,6 +2727,7 @@ int gik_template_get_info(const gik_template *t, gik_template_info *info) {
   info->has_pipeline = t->has_pipe ? 1 : 0;
   info->prepare_is_block = t->prep_block ? 1 : 0;
   info->node_per_lane = t->is_npt ? t->npt_variant->NW : 0;
+  info->problems_per_wave = t->is_block ? 0 : ((t->quad_solve && !(t->dbg & (1 | 8192))) ? gik::QUAD_SLOTS : 1);
   if (t->is_npt) {
     info->waves_per_cu = t->npt_waves_per_cu;
     info->lds_bytes = (int32_t)t->npt_smem;

@@ -83,7 +83,8 @@ typedef struct {
                                 workgroup path: 64 = closed form for rigid cliques from 4 nodes
                                 up (default: 16 nodes); 128 / 256 = older spellings of
                                 clique_closed_form = GIK_CLIQUE_OFF / GIK_CLIQUE_DENSE; 2048 = node-per-lane
-                                kernel with one wavefront per problem (two nodes per lane); 512 = neither round-robin
+                                kernel with one wavefront per problem (two nodes per lane); 8192 = planar graphs: one
+                                problem per wavefront instead of four; 512 = neither round-robin
                                 slicing nor tail spreading on the wavefront kernel, 1024 = no slicing
                                 (scheduling measures of large batches, bit-neutral: tests compare) */
   /* which of the reference's two solvers gik_solve_batch runs (riemannian_solver.py:40-65):
@@ -197,7 +198,9 @@ typedef struct {
   int32_t node_per_lane;       /* != 0: an is_block graph solved by the node-per-lane kernel instead of the
                                   512-thread workgroup kernel; the value is its wavefronts per problem (2: one
                                   node per lane, 1: two nodes per lane)                                   */
-  int32_t reserved[3];
+  int32_t problems_per_wave;   /* 4: planar graph (k = 2, <= 16 nodes, <= 6 terms per node) whose trust-region
+                                  solves run four problems to a wavefront (rtr_quad_kernel); else 1 (0: block) */
+  int32_t reserved[2];
 } gik_template_info;
 int gik_template_get_info(const gik_template *t, gik_template_info *info);
 

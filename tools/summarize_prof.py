@@ -48,7 +48,7 @@ for k, cs in summary.items():
     cs["_dispatches"] = len(next(iter(per[k].values())))
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc_per_launch.json"), "w"), indent=1)
 
-solve = next(k for k in summary if "rtr_wave_kernel" in k or "rtr_block_kernel" in k or "rtr_npt_kernel" in k)
+solve = next(k for k in summary if "rtr_wave_kernel" in k or "rtr_block_kernel" in k or "rtr_npt_kernel" in k or "rtr_quad_kernel" in k)
 fetch = summary[solve]["FETCH_SIZE"] * 1024 * 2
 write = summary[solve]["WRITE_SIZE"] * 1024
 json.dump({"kernel": solve, "bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch,
