@@ -93,9 +93,11 @@ def test_operator_properties(torch_cuda, name):
 
 
 # ---- trust-region trajectories -----------------------------------------------------------------
+@pytest.mark.parametrize("per_wave", [4, 1])
 @pytest.mark.parametrize("name", SCENARIOS_2D)
-def test_trajectory_planar_identical_to_oracle(torch_cuda, name):
-    """Planar solves are well conditioned: every discrete decision (inner-iteration count, tCG
+def test_trajectory_planar_identical_to_oracle(torch_cuda, name, per_wave):
+    """(Both planar solve kernels: four problems per wavefront -- the default -- and one, debug_flags 8192.)
+    Planar solves are well conditioned: every discrete decision (inner-iteration count, tCG
     stop reason, accept flag, radius) equals the oracle's, and f agrees to 1e-7, for as long as
     the iterate is above the round-off floor (f >= 1e-14).  Below it the outcome of a tCG call
     hinges on whether CG's finite-termination collapse survives round-off (the reference's
@@ -104,7 +106,8 @@ def test_trajectory_planar_identical_to_oracle(torch_cuda, name):
     from graphik_amd.graphs.graph_planar import joint_variables_planar_batch
     d = load_golden(name)
     robot, graph = make_graph(name)
-    T = _template(d)
+    T = _template(d, debug_flags=0 if per_wave == 4 else 8192)
+    assert T.info["problems_per_wave"] == per_wave
     use_lim = bool(int(d["use_limits"]))
     r = T.solve(d["Y_init"], T.targets_from_D(d["D_goal"]), trace_cap=48)
     tr = {k: v.cpu().numpy() for k, v in r["trace"].items()}
@@ -881,6 +884,81 @@ def test_block_path_trajectories_match_wave_path(torch_cuda, name, flags, path):
         assert all(p >= min(m, q) for p, q in zip(part, n)), (part, n)
         assert np.median(part) >= m + 2, part
 
+
+# ---- four planar problems per wavefront (rtr_quad_kernel) ---------------------------------------
+@pytest.mark.parametrize("name", SCENARIOS_2D)
+def test_quad_kernel_against_one_problem_per_wavefront(torch_cuda, name):
+    """The same solves on both planar kernels.  They sum inner products in different orders (per node
+    first / per unknown), so the bar is that of two renderings of the algorithm: every decision of the
+    first 8 outer iterations identical, the iteration counts equal, the points equal to 1e-9; and a slot
+    of the wavefront must not care what its three neighbours do: every problem of a batch of 37 (ragged:
+    the last wavefront holds one problem) ends bit-identical to the same problem solved alone."""
+    from graphik_amd.engine import Template
+    d = load_golden(name)
+    kw = dict(k=2, use_limits=bool(int(d["use_limits"])))
+    Tq = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], **kw)
+    Tw = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"debug_flags": 8192}, **kw)
+    assert Tq.info["problems_per_wave"] == 4 and Tw.info["problems_per_wave"] == 1
+    tg = Tq.targets_from_D(d["D_goal"])
+    rq = Tq.solve(d["Y_init"], tg, trace_cap=32)
+    rw = Tw.solve(d["Y_init"], tg, trace_cap=32)
+    for key in ("numit", "stop", "accept", "Delta"):
+        assert np.array_equal(rq["trace"][key].cpu().numpy()[:, :8], rw["trace"][key].cpu().numpy()[:, :8]), key
+    for key in ("iterations", "stop", "n_accept"):
+        assert np.array_equal(rq[key].cpu().numpy(), rw[key].cpu().numpy()), key
+    assert np.array_equal(rq["inner_total"].cpu().numpy(), rq["inner_executed"].cpu().numpy())
+    assert np.abs(rq["x"].cpu().numpy() - rw["x"].cpu().numpy()).max() < 1e-9
+    assert float(rq["f"].max()) < 1e-11
+    # ragged batch, every problem against itself alone
+    G = len(d["Y_init"])
+    rng = np.random.RandomState(5)
+    idx = rng.randint(0, G, size=37)
+    Y0 = d["Y_init"][idx] + 1e-3 * rng.randn(37, *d["Y_init"].shape[1:])
+    tgb = np.asarray(tg)[idx]
+    rb = Tq.solve(Y0, tgb)
+    xb = rb["x"].cpu().numpy()
+    for g in (0, 1, 17, 35, 36):
+        r1 = Tq.solve(Y0[g:g + 1], tgb[g:g + 1])
+        assert np.array_equal(r1["x"].cpu().numpy()[0], xb[g]), g
+        for key in ("f", "gradnorm", "iterations", "inner_total", "stop", "n_accept", "stepsize"):
+            assert r1[key].cpu().numpy()[0] == rb[key].cpu().numpy()[g], (g, key)
+
+
+def test_quad_kernel_stopping_rules(torch_cuda):
+    """maxiter (stop 1, counters as the reference leaves them), a NaN start point (stop 2, no iteration, the
+    other slots of the wavefront unaffected) and solves pushed far below the round-off floor."""
+    from graphik_amd.engine import Template
+    d = load_golden("planar10_limits_pi")
+    kw = dict(k=2, use_limits=True)
+    tg = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], **kw).targets_from_D(d["D_goal"])
+    G = len(d["Y_init"])
+    for flags in (0, 8192):
+        T3 = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"maxiter": 3, "debug_flags": flags}, **kw)
+        r = T3.solve(d["Y_init"], tg, trace_cap=8)
+        assert np.all(r["iterations"].cpu().numpy() == 3) and np.all(r["stop"].cpu().numpy() == 1)
+        if flags == 0:
+            ref = r
+        else:
+            assert np.array_equal(r["inner_total"].cpu().numpy(), ref["inner_total"].cpu().numpy())
+            assert np.allclose(r["x"].cpu().numpy(), ref["x"].cpu().numpy(), atol=1e-11)
+    T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], **kw)
+    Y0 = np.concatenate([d["Y_init"]] * 3)[:21].copy()
+    tgb = np.concatenate([np.asarray(tg)] * 3)[:21]
+    clean = T.solve(Y0, tgb)
+    Y0n = Y0.copy()
+    Y0n[5, 3, 1] = np.nan
+    r = T.solve(Y0n, tgb)
+    st = r["stop"].cpu().numpy()
+    assert st[5] == 2 and int(r["iterations"][5]) == 0
+    keep = np.arange(21) != 5
+    assert np.array_equal(st[keep], clean["stop"].cpu().numpy()[keep])
+    assert np.array_equal(r["x"].cpu().numpy()[keep], clean["x"].cpu().numpy()[keep])
+    # far below the round-off floor (mingradnorm = 0: every slot runs to maxiter = 40, steps rejected for dozens
+    # of passes, radii shrinking to 1e-20): the masked loops must neither hang nor produce a NaN
+    Tm = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"maxiter": 40, "mingradnorm": 0.0}, **kw)
+    rm = Tm.solve(Y0, tgb)
+    assert np.all(rm["iterations"].cpu().numpy() == 40) and np.all(rm["stop"].cpu().numpy() == 1)
+    assert float(rm["f"].max()) < 1e-20 and np.all(np.isfinite(rm["x"].cpu().numpy()))
 
 def test_clique_closed_form_against_direct_sum(torch_cuda):
     """Table scene, random points and directions (not only the golden ones): the closed form of
