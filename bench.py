@@ -460,6 +460,8 @@ class Bench:
             kernel_name = "rtr_npt_kernel (node per lane, %d wavefront(s) per problem)" % int(info["node_per_lane"])
         elif info and info.get("is_block"):
             kernel_name = f"rtr_block_kernel<{k}>"
+        elif info and info.get("problems_per_wave", 1) == 4:
+            kernel_name = f"rtr_quad_kernel<{info['max_terms_per_node']}> (four planar problems per wavefront)"
         else:
             kernel_name = f"rtr_wave_kernel<{k},{info['max_terms_per_node'] if info else prob.template.maxdeg}>"
         flops_exec = executed_flops(N, k, T, info if anch is None else None, lowrank_local,

@@ -1,0 +1,479 @@
+// graphik_amd/csrc/gik_prep_quad.hip.h -- per-goal pre-processing, four goals per wavefront
+//
+// prep_wave_kernel (gik_prep.hip.h) gives a goal a whole wavefront.  For a graph of at most 16 nodes
+// (the planar chains: N = 13) that is 64 lanes for matrices of 13 rows, and every rotation parameter,
+// Householder scalar and loop counter is a wave-wide instruction for one number: measured, round 4,
+// 34 k instructions per goal, 3.6 of the 5.1 ms of BASELINE configs[4].  Here a wavefront holds FOUR
+// goals in the lane layout of the planar solve kernel (gik_quad.hip.h):
+//
+//   lane l = 16 r + 4 b + i   ->   goal slot b (0..3), matrix row n = 4 r + i (0..15)
+//
+// so a lane owns a ROW of its goal's N x N matrices (LDS, odd row stride: the 16 rows of a goal fall
+// into different banks), per-goal reductions are two v_mfma_f64_4x4x4 (quad_sum), and one
+// instruction stream serves four goals.  Same phases and -- per matrix element -- the same
+// operations in the same order as prep_wave_kernel (ProblemGraph.from_pose + graph_complete_edges,
+// graph_base.py:146-180, dgp.py:124-147; bound smoothing, dgp.py:192-231;
+// RiemannianSolver.generate_initialization, riemannian_solver.py:67-75), with two differences that
+// stay at round-off: the per-goal sums of the Jacobi threshold and of the Householder reflectors are
+// taken in another order, and the K x K Jacobi of linear_projection runs the round-robin schedule
+// of the LARGEST K among the wavefront's four goals (a goal with a smaller K sees extra pairs whose
+// off-diagonal entry is exactly zero: skipped).  Three matrices per goal instead of five (each
+// phase overwrites what the previous one no longer needs): 18 KB of LDS per wavefront at N = 13.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gik_prep.hip.h"
+#include "gik_quad.hip.h"
+
+namespace gik {
+
+constexpr int PREPQ_MAXN = QUAD_NODES;
+
+// doubles between the matrices of neighbouring goals: N rows of odd stride S = N | 1, padded to 24 mod 32 doubles
+// (48 of the 64 four-byte banks).  With the 16 rows of a goal at odd stride the rows a half-wave touches in the
+// column phase (lane = row, one column) fall into 8 distinct bank pairs per goal, and the four goals' sets -- like
+// the four 16-bank runs of the row phase (lane = column) -- are disjoint exactly when the goals sit 16 banks apart.
+__host__ __device__ inline int prep_quad_goal_stride(int N) {
+  const int NS = N * (N | 1);
+  return NS + ((24 - NS % 32) + 32) % 32;
+}
+__host__ __device__ inline size_t prep_quad_lds_bytes(int N, int n_gd) {
+  return sizeof(double) * ((size_t)12 * prep_quad_goal_stride(N) + 4 * (size_t)((n_gd + 1) & ~1) + 5 * 64) + sizeof(int) * 64;
+}
+
+// does any lane of this lane's goal slot hold `c`?
+__device__ inline bool quad_any_in_goal(bool c, int slot) {
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
+  return (m & (0x000F000F000F000Full << (4 * slot))) != 0ull;
+}
+
+// round-robin (chess tournament) pair m of round r among ne (even) players, rr_pair without its divisions
+// (r + m < 2 (ne - 1)); p < q, q = ne - 1 is the bye of an odd matrix size
+__host__ __device__ constexpr int quad_rr_p(int ne, int r, int m) {
+  const int a = m == 0 ? ne - 1 : (r + m >= ne - 1 ? r + m - (ne - 1) : r + m);
+  const int b = m == 0 ? r : (r - m < 0 ? r - m + (ne - 1) : r - m);
+  return a < b ? a : b;
+}
+__host__ __device__ constexpr int quad_rr_q(int ne, int r, int m) {
+  const int a = m == 0 ? ne - 1 : (r + m >= ne - 1 ? r + m - (ne - 1) : r + m);
+  const int b = m == 0 ? r : (r - m < 0 ? r - m + (ne - 1) : r - m);
+  return a < b ? b : a;
+}
+
+// rotation of the pair (p, q) of a symmetric matrix, as in jacobi_lds: t = sgn(th) / (|th| + sqrt(th^2 + 1)),
+// c = 1 / sqrt(t^2 + 1), s = t c with reciprocal / reciprocal-square-root Newton steps
+__device__ inline bool quad_rotation(double app, double aqq, double apq, double thr, double &c, double &s) {
+  c = 1.0;
+  s = 0.0;
+  if (!(fabs(apq) > thr)) return false;
+  const double th = (aqq - app) * (0.5 * frcp(apq));
+  const double h2 = fma(th, th, 1.0);
+  const double t = (th >= 0.0 ? 1.0 : -1.0) * frcp(fabs(th) + h2 * frsqrt(h2));
+  c = frsqrt(fma(t, t, 1.0));
+  s = t * c;
+  return true;
+}
+
+// Cyclic Jacobi (see jacobi_lds) on the leading n x n block of this goal's symmetric matrix A (row
+// stride S), V accumulates the eigenvectors as columns.  n is wave-uniform; a goal whose matrix is
+// non-zero in a smaller leading block only passes the larger n as well.  Lane `i` is row / column i
+// of its goal; cs: 8 (c, s) pairs of this goal.
+__device__ inline void quad_jacobi(double *A, double *V, int S, int n, int sweeps, double2 *cs, int slot, int i) {
+  const int ne = n + (n & 1), np = ne / 2;
+  __builtin_amdgcn_wave_barrier();
+  double fro = 0.0;
+  if (i < n)
+    for (int j = 0; j < n; ++j) fro = fma(A[i * S + j], A[i * S + j], fro);
+  const double thr = 1e-16 * sqrt(quad_sum(fro));
+  const unsigned long long mine = 0x000F000F000F000Full << (4 * slot);
+  for (int sw = 0; sw < sweeps; ++sw) {
+    bool rotated = false;
+    for (int r = 0; r < ne - 1; ++r) {
+      bool sig = false;
+      if (i < np) {
+        const int p = quad_rr_p(ne, r, i), q = quad_rr_q(ne, r, i);
+        double c = 1.0, s = 0.0;
+        if (q < n) sig = quad_rotation(A[p * S + p], A[q * S + q], A[p * S + q], thr, c, s);
+        cs[i] = make_double2(c, s);
+      }
+      const unsigned long long anysig = __builtin_amdgcn_ballot_w64(sig);
+      if (anysig == 0ull) continue;                      // nothing to rotate in this round, in any goal
+      rotated = rotated || (anysig & mine) != 0ull;
+      __builtin_amdgcn_wave_barrier();
+      // (a goal without a significant pair in this round multiplies by c = 1, s = 0: exact)
+      for (int m = 0; m < np; ++m) {                     // column phase: lane = row, A and V
+        const int p = quad_rr_p(ne, r, m), q = quad_rr_q(ne, r, m);   // (wave-uniform)
+        if (q >= n) continue;
+        const double2 r2 = cs[m];
+        const double c = r2.x, s = r2.y;
+        if (i < n) {
+          const double ap = A[i * S + p], aq = A[i * S + q];
+          A[i * S + p] = c * ap - s * aq;
+          A[i * S + q] = s * ap + c * aq;
+          const double vp = V[i * S + p], vq = V[i * S + q];
+          V[i * S + p] = c * vp - s * vq;
+          V[i * S + q] = s * vp + c * vq;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int m = 0; m < np; ++m) {                     // row phase on A: lane = column
+        const int p = quad_rr_p(ne, r, m), q = quad_rr_q(ne, r, m);
+        if (q >= n) continue;
+        const double2 r2 = cs[m];
+        const double c = r2.x, s = r2.y;
+        if (i < n) {
+          const double ap = A[p * S + i], aq = A[q * S + i];
+          A[p * S + i] = c * ap - s * aq;
+          A[q * S + i] = s * ap + c * aq;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (__builtin_amdgcn_ballot_w64(rotated) == 0ull) break;   // every goal of the wavefront has converged
+  }
+}
+
+// The same for a matrix size known at compile time (the whole N x N matrix): the rounds are unrolled, every
+// pair a constant, so a lane's accesses are its row (column) address plus an immediate offset -- each phase of a
+// round loads everything it needs, then computes, then stores: one LDS round trip per phase where the loop above
+// takes one per pair (the compiler has to assume that a pair's stores alias the next pair's loads).
+template <int N>
+__device__ inline void quad_jacobi_fixed(double *A, double *V, int sweeps, double2 *cs, int slot, int i) {
+  constexpr int S = N | 1, NE = N + (N & 1), NP = NE / 2;
+  __builtin_amdgcn_wave_barrier();
+  const bool row = i < N;
+  double *Ar = A + i * S, *Vr = V + i * S, *Ac = A + i;   // this lane's row of A and V, column of A
+  // V is only ever touched row by row, and with constant column indices a row can stay in registers for the
+  // whole decomposition (it starts as the identity and is written out once, at the end): a third less LDS
+  // traffic per round -- the pipe all wavefronts of a CU share, and what bounds this loop
+  double vr[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) vr[j] = (i == j) ? 1.0 : 0.0;
+  double fro = 0.0;
+  if (row) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) fro = fma(Ar[j], Ar[j], fro);
+  }
+  const double thr = 1e-16 * sqrt(quad_sum(fro));
+  const unsigned long long mine = 0x000F000F000F000Full << (4 * slot);
+  // the diagonal / off-diagonal entries lane m < NP needs for its rotation of round r: per-lane offsets
+  for (int sw = 0; sw < sweeps; ++sw) {
+    bool rotated = false;
+#pragma unroll
+    for (int r = 0; r < NE - 1; ++r) {
+      bool sig = false;
+      if (i < NP) {
+        int p = 0, q = NE - 1;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+          p = (i == m) ? quad_rr_p(NE, r, m) : p;
+          q = (i == m) ? quad_rr_q(NE, r, m) : q;
+        }
+        double c = 1.0, s = 0.0;
+        if (q < N) sig = quad_rotation(A[p * S + p], A[q * S + q], A[p * S + q], thr, c, s);
+        cs[i] = make_double2(c, s);
+      }
+      const unsigned long long anysig = __builtin_amdgcn_ballot_w64(sig);
+      if (anysig == 0ull) continue;
+      rotated = rotated || (anysig & mine) != 0ull;
+      __builtin_amdgcn_wave_barrier();
+      double2 rc[NP];
+#pragma unroll
+      for (int m = 0; m < NP; ++m) rc[m] = cs[m];
+      if (row) {                                           // column phase: lane = row, A and V
+        double ap[NP], aq[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m)
+          if (quad_rr_q(NE, r, m) < N) {
+            ap[m] = Ar[quad_rr_p(NE, r, m)];
+            aq[m] = Ar[quad_rr_q(NE, r, m)];
+          }
+#pragma unroll
+        for (int m = 0; m < NP; ++m)
+          if (quad_rr_q(NE, r, m) < N) {
+            const double c = rc[m].x, s = rc[m].y;
+            Ar[quad_rr_p(NE, r, m)] = c * ap[m] - s * aq[m];
+            Ar[quad_rr_q(NE, r, m)] = s * ap[m] + c * aq[m];
+            const double vp = vr[quad_rr_p(NE, r, m)], vq = vr[quad_rr_q(NE, r, m)];
+            vr[quad_rr_p(NE, r, m)] = c * vp - s * vq;
+            vr[quad_rr_q(NE, r, m)] = s * vp + c * vq;
+          }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (row) {                                           // row phase on A: lane = column
+        double ap[NP], aq[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m)
+          if (quad_rr_q(NE, r, m) < N) {
+            ap[m] = Ac[quad_rr_p(NE, r, m) * S];
+            aq[m] = Ac[quad_rr_q(NE, r, m) * S];
+          }
+#pragma unroll
+        for (int m = 0; m < NP; ++m)
+          if (quad_rr_q(NE, r, m) < N) {
+            const double c = rc[m].x, s = rc[m].y;
+            Ac[quad_rr_p(NE, r, m) * S] = c * ap[m] - s * aq[m];
+            Ac[quad_rr_q(NE, r, m) * S] = s * ap[m] + c * aq[m];
+          }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (__builtin_amdgcn_ballot_w64(rotated) == 0ull) break;
+  }
+  if (row) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) Vr[j] = vr[j];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Number of eigenvalues > tau of this goal's symmetric N x N matrix A (destroyed): Householder
+// reduction to tridiagonal form + a Sturm count (see count_eigs_above_lds).  hv, hw: 16 doubles each.
+__device__ inline int quad_count_eigs_above(double *A, int S, int N, double tau, double *hv, double *hw, int i) {
+  for (int k = 0; k + 2 < N; ++k) {
+    const bool mine = i > k && i < N;
+    const double x = mine ? A[i * S + k] : 0.0;
+    const double x0 = A[(k + 1) * S + k];
+    const double s0 = quad_sum(x * x), s1 = quad_sum((mine && i > k + 1) ? x * x : 0.0);
+    const bool go = s1 != 0.0;                       // else: column already tridiagonal (goal-uniform)
+    const double alpha = x0 > 0.0 ? -sqrt(s0) : sqrt(s0);
+    const double vj = mine ? (i == k + 1 ? x - alpha : x) : 0.0;
+    const double beta = 1.0 / (s0 - alpha * x0);     // 2 / v'v
+    __builtin_amdgcn_wave_barrier();
+    hv[i] = vj;
+    __builtin_amdgcn_wave_barrier();
+    double pj = 0.0;
+    if (mine)
+      for (int c = k + 1; c < N; ++c) pj = fma(A[i * S + c], hv[c], pj);
+    pj *= beta;
+    const double Kc = 0.5 * beta * quad_sum(vj * pj);
+    const double wj = pj - Kc * vj;
+    hw[i] = mine ? wj : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    if (mine && go) {
+      for (int c = k + 1; c < N; ++c) {
+        const int e = i * S + c;
+        A[e] = A[e] - vj * hw[c] - wj * hv[c];
+      }
+      if (i == k + 1) A[(k + 1) * S + k] = alpha;    // sub-diagonal entry of the tridiagonal form
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  int below = 0;
+  double q = A[0] - tau;
+  below += q < 0.0;
+  for (int r = 1; r < N; ++r) {
+    const double bb = A[r * S + r - 1];
+    if (q == 0.0) q = 1e-300;
+    q = A[r * S + r] - tau - bb * bb / q;
+    below += q < 0.0;
+  }
+  return N - below;
+}
+
+__global__ void __launch_bounds__(WAVE, 2) prep_quad_kernel(PrepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const PipeConst &pc = a.pc;
+  const int N = pc.N, K = pc.K, S = N | 1, D = K + 1;
+  const int lane = threadIdx.x, slot = (lane >> 2) & 3, i = ((lane >> 4) << 2) | (lane & 3);
+  const bool has = i < N;
+  const int n_gd = 2 * pc.n_ee * pc.n_anchor + pc.n_gg, n_gd_pad = (n_gd + 1) & ~1;
+  // three matrices per goal: M0 = upper bounds -> eigenvectors; M1 = lower-bound table -> lower bounds
+  // -> D_rand -> MDS factor X; M2 = work matrix
+  const int GS = prep_quad_goal_stride(N);
+  double *M0 = smem + (size_t)slot * GS;
+  double *M1 = smem + (size_t)(4 + slot) * GS;
+  double *M2 = smem + (size_t)(8 + slot) * GS;
+  double *gd = smem + (size_t)12 * GS + (size_t)slot * n_gd_pad;
+  double *vec = smem + (size_t)12 * GS + 4 * (size_t)n_gd_pad;
+  double *ev = vec + slot * 16, *sg = vec + 64 + slot * 16, *hv = vec + 128 + slot * 16, *hw = vec + 192 + slot * 16;
+  double2 *cs = reinterpret_cast<double2 *>(vec + 256 + slot * 16);
+  int *rk = reinterpret_cast<int *>(vec + 320) + slot * 16;
+
+  const int groups = (a.B + QUAD_SLOTS - 1) / QUAD_SLOTS;
+  for (int g4 = blockIdx.x; g4 < groups; g4 += gridDim.x) {
+    const int b_raw = g4 * QUAD_SLOTS + slot;
+    const bool valid = b_raw < a.B;
+    const int b = valid ? b_raw : a.B - 1;           // (an empty slot of the last group repeats the last goal, unstored)
+    const double *Tg = a.T_goal + (size_t)b * D * D * pc.n_ee;
+    double *U = M0, *L = M1, *A = M2;
+    __builtin_amdgcn_wave_barrier();
+    if (has)
+      for (int j = 0; j < N; ++j) {
+        const double lo = pc.base_lower[i * N + j], up = pc.base_upper[i * N + j];
+        U[i * S + j] = (i == j) ? 0.0 : (up == up ? up : INFINITY);
+        L[i * S + j] = (i == j) ? 0.0 : (lo == lo ? lo : -INFINITY);
+      }
+    __builtin_amdgcn_wave_barrier();
+    // goal nodes (_pose_goal) and the distances graph_complete_edges gives them (dgp.py:124-147)
+    for (int idx = i; idx < n_gd; idx += QUAD_NODES) {
+      int an, gn;
+      const double d = goal_distance(pc, Tg, idx, an, gn);
+      gd[idx] = d;
+      U[an * S + gn] = U[gn * S + an] = d;
+      L[an * S + gn] = L[gn * S + an] = d;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // per-term targets: squared goal distances for the goal edges, template constants otherwise
+    if (valid)
+      for (int t = i; t < pc.T; t += QUAD_NODES) {
+        const int src = pc.term_src[t];
+        const double g = src >= 0 ? gd[src] : 0.0;
+        a.targets[(size_t)b * pc.T + t] = src >= 0 ? g * g : pc.term_static[t];
+      }
+#ifdef GIK_DEV
+    if (a.stop_phase == 1) continue;
+#endif
+    // ---- bound smoothing: ub = APSP(UPPER) (Floyd-Warshall; row m and column m do not change in step m), then
+    //      lb[u][v] = max(0, max_{a,b} LOWER[a][b] - ub[u][a] - ub[b][v])   (see dgp.py)
+    for (int m = 0; m < N; ++m) {
+      if (has) {
+        const double uim = U[i * S + m];
+        for (int j = 0; j < N; ++j) {
+          const double cand = uim + U[m * S + j];
+          if (cand < U[i * S + j]) U[i * S + j] = cand;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#ifdef GIK_DEV
+    if (a.stop_phase == 2) continue;
+#endif
+    if (has)
+      for (int c = 0; c < N; ++c) {                  // A[u][b] = max_a (L[a][b] - U[u][a])
+        double best = -INFINITY;
+        for (int q = 0; q < N; ++q) best = fmax(best, L[q * S + c] - U[i * S + q]);
+        A[i * S + c] = best;
+      }
+    __builtin_amdgcn_wave_barrier();
+    if (has)
+      for (int c = 0; c < N; ++c) {                  // lb[u][v] (over L: the table is no longer needed)
+        double best = 0.0;
+        for (int q = 0; q < N; ++q) best = fmax(best, A[i * S + q] - U[q * S + c]);
+        L[i * S + c] = best;
+      }
+    __builtin_amdgcn_wave_barrier();
+#ifdef GIK_DEV
+    if (a.stop_phase == 3) continue;
+#endif
+    // ---- generate_initialization: D_rand = (lb + 0.9 (ub - lb))^2, Gram = -1/2 J D J
+    double *X = M1, *V = M0;
+    if (has) {
+      for (int j = 0; j < N; ++j) {
+        const double lbv = L[i * S + j], d = lbv + 0.9 * (U[i * S + j] - lbv);
+        X[i * S + j] = d * d;
+      }
+      double s = 0.0;                                // (a second pass, as in prep_wave_kernel: the squares are
+      for (int j = 0; j < N; ++j) s += X[i * S + j]; //  rounded before they are summed, no fused multiply-add)
+      ev[i] = s / N;
+    }
+    __builtin_amdgcn_wave_barrier();
+    double mean = 0.0;
+    for (int j = 0; j < N; ++j) mean += ev[j];
+    mean /= N;
+    if (has)
+      for (int j = 0; j < N; ++j) {
+        A[i * S + j] = -0.5 * (X[i * S + j] - ev[i] - ev[j] + mean);
+        V[i * S + j] = (i == j) ? 1.0 : 0.0;
+      }
+#ifdef GIK_DEV
+    if (a.stop_phase == 4) continue;
+#endif
+    if (N == 13) quad_jacobi_fixed<13>(A, V, a.sweeps, cs, slot, i);   // (the 10-link chains of BASELINE configs[4])
+    else quad_jacobi(A, V, S, N, a.sweeps, cs, slot, i);
+#ifdef GIK_DEV
+    if (a.stop_phase == 5) continue;
+#endif
+    // ---- factor(): clip, scale by sqrt(lambda), order descending (fliplr of ascending)
+    if (has) ev[i] = A[i * S + i];
+    __builtin_amdgcn_wave_barrier();
+    if (has) {
+      rk[i] = desc_rank(ev, N, i);
+      // canonical sign: the entry of largest magnitude (first on ties) is positive (see prep_wave_kernel)
+      double big = 0.0, sgn = 1.0;
+      for (int r = 0; r < N; ++r) {
+        const double v = V[r * S + i];
+        if (fabs(v) > big) {
+          big = fabs(v);
+          sgn = v < 0.0 ? -1.0 : 1.0;
+        }
+      }
+      sg[i] = sgn * sqrt(fmax(ev[i], 0.0));
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (has)
+      for (int c = 0; c < N; ++c) X[i * S + rk[c]] = V[i * S + c] * sg[c];
+    __builtin_amdgcn_wave_barrier();
+    // ---- MDS(): K = #eigenvalues > eps of eigh(x), i.e. of the symmetric matrix read from the
+    //      LOWER triangle of the non-symmetric factor x (dgp.py:166-167, numpy UPLO='L')
+    if (has)
+      for (int j = 0; j < N; ++j) A[i * S + j] = (i >= j) ? X[i * S + j] : X[j * S + i];
+    __builtin_amdgcn_wave_barrier();
+#ifdef GIK_DEV
+    if (a.stop_phase == 6) continue;
+#endif
+    const int Kc = quad_count_eigs_above(A, S, N, 1e-8, hv, hw, i);
+    if (a.K_out && valid && i == 0) a.K_out[b] = Kc;
+    __builtin_amdgcn_wave_barrier();
+#ifdef GIK_DEV
+    if (a.stop_phase == 7) continue;
+#endif
+    // ---- linear_projection (dgp.py:174-183): scatter of the edge differences of the first Kc
+    //      columns, its top-`dim` eigenvectors
+    if (has)
+      for (int c = Kc; c < N; ++c) X[i * S + c] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    if (has)
+      for (int c = 0; c < N; ++c) {
+        double s = 0.0;
+        if (i < Kc && c < Kc) {
+          for (int p = 0; p < pc.n_pairs; ++p) {
+            const int pi = pc.pair_i[p], pj = pc.pair_j[p];
+            s = fma(X[pi * S + i] - X[pj * S + i], X[pi * S + c] - X[pj * S + c], s);
+          }
+        }
+        A[i * S + c] = 2.0 * s;  // the reference sums both (i,j) and (j,i)
+        V[i * S + c] = (i == c) ? 1.0 : 0.0;
+      }
+#ifdef GIK_DEV
+    if (a.stop_phase == 8) continue;
+#endif
+    // the largest block among the four goals sets the schedule (wave-uniform)
+    const int n2 = Kc > 1 ? Kc : 2;
+    const int n2max = max(max(__builtin_amdgcn_readlane(n2, 0), __builtin_amdgcn_readlane(n2, 4)),
+                          max(__builtin_amdgcn_readlane(n2, 8), __builtin_amdgcn_readlane(n2, 12)));
+    quad_jacobi(A, V, S, n2max, a.sweeps, cs, slot, i);
+#ifdef GIK_DEV
+    if (a.stop_phase == 9) continue;
+#endif
+    if (has) ev[i] = (i < Kc) ? A[i * S + i] : -INFINITY;
+    __builtin_amdgcn_wave_barrier();
+    if (has) {
+      rk[i] = desc_rank(ev, N, i);
+      double big = 0.0, sgn = 1.0;
+      for (int r = 0; r < N; ++r) {
+        const double v = V[r * S + i];
+        if (fabs(v) > big) {
+          big = fabs(v);
+          sgn = v < 0.0 ? -1.0 : 1.0;
+        }
+      }
+      sg[i] = sgn;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // Y = X * W, W = the K eigenvectors of largest eigenvalue
+    if (has && valid)
+      for (int dcol = 0; dcol < K; ++dcol) {
+        int col = 0;
+        for (int c = 0; c < N; ++c) col = (rk[c] == dcol) ? c : col;
+        double s = 0.0;
+        for (int c = 0; c < N; ++c) s += X[i * S + c] * V[c * S + col];
+        a.Y_init[(size_t)b * N * K + i * K + dcol] = s * sg[col];
+      }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace gik

@@ -22,6 +22,7 @@
 #include "gik_npt.hip.h"
 #include "gik_quad.hip.h"
 #include "gik_prep.hip.h"
+#include "gik_prep_quad.hip.h"
 #include "gik_rcg.hip.h"
 #include "gik_rtr.hip.h"
 #include "gik_rtrv.hip.h"
@@ -1413,6 +1414,9 @@ struct gik_template {
   size_t prep_smem;
   int prep_waves_per_cu = 8;   // resident prepare waves (workgroups on the block variant) per CU
   bool prep_block = false;
+  bool prep_quad = false;      // four goals per wavefront (prep_quad_kernel: graphs of at most 16 nodes)
+  size_t prep_quad_smem = 0;
+  int prep_quad_waves_per_cu = 8;
   bool prep_a_lds = false;     // block variant: work matrix in LDS
   bool prep_no_compress = false;   // block variant: full N x N Jacobi even where the Gram matrix is rank deficient
   double *prep_ws = nullptr;   // [n_cu * prep_waves_per_cu][5][N*N] (block variant)
@@ -2202,6 +2206,7 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
     for (int k = 0; k <= n; ++k) path[k] = k;
   }
   pc.ee_path = upload(t, path.data(), path.size(), ok);
+
   pc.gg_a = pc.n_gg ? upload(t, d->goal_pair_a, pc.n_gg, ok) : nullptr;
   pc.gg_b = pc.n_gg ? upload(t, d->goal_pair_b, pc.n_gg, ok) : nullptr;
   if (2 * n_ee * d->n_anchor + pc.n_gg > 2 * PREP_MAXA + 16) return fail("too many anchor-goal pairs");
@@ -2253,6 +2258,19 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
       occ = 8;
     if (const char *e = getenv("GIK_PREP_WAVES_PER_CU")) occ = atoi(e);   // developer override
     t->prep_waves_per_cu = std::max(1, std::min(occ, 32));
+    if (N <= PREPQ_MAXN && !getenv("GIK_NO_PREP_QUAD")) {
+      t->prep_quad_smem = prep_quad_lds_bytes(N, 2 * n_ee * d->n_anchor + pc.n_gg);
+      int qocc = 0;
+      if (t->prep_quad_smem <= 40 * 1024 &&
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&qocc, prep_quad_kernel, WAVE, t->prep_quad_smem) == hipSuccess &&
+          qocc >= 1) {
+        t->prep_quad = true;
+        if (const char *e = getenv("GIK_PREP_WAVES_PER_CU")) qocc = atoi(e);
+        t->prep_quad_waves_per_cu = std::max(1, std::min(qocc, 32));
+      } else {
+        (void)hipGetLastError();
+      }
+    }
   }
   t->has_pipe = true;
   return 0;
@@ -2301,6 +2319,10 @@ int gik_prepare_batch_debug(const gik_template *t, const double *d_T_goal, int B
                          t->prep_ws);
     HIP_OK(hipEventRecord(mt->prep_done, (hipStream_t)stream));
     mt->prep_pending = true;
+  } else if (t->prep_quad && !a.dbg_lb && !a.dbg_eig) {
+    // (the diagnostics -- bounds and spectra of gik_prepare_batch_debug -- come from the one-goal-per-wavefront kernel)
+    const int qgrid = std::min((B + QUAD_SLOTS - 1) / QUAD_SLOTS, t->n_cu * t->prep_quad_waves_per_cu);
+    hipLaunchKernelGGL(prep_quad_kernel, dim3(qgrid), dim3(WAVE), t->prep_quad_smem, (hipStream_t)stream, a);
   } else
     hipLaunchKernelGGL(prep_wave_kernel, dim3(grid), dim3(WAVE), t->prep_smem, (hipStream_t)stream,
                        a);

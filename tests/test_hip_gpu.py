@@ -726,6 +726,9 @@ def test_block_prepare_kernel_equals_wave_kernel(torch_cuda, monkeypatch, name, 
     graphs of 124..128 nodes get)."""
     if a_global:
         monkeypatch.setenv("GIK_PREP_A_GLOBAL", "1")
+    # (graphs of at most 16 nodes default to the four-goals-per-wavefront kernel, which sums two of its inner
+    # products in another order -- test_quad_prepare_kernel_against_wave_kernel; this test is about the other two)
+    monkeypatch.setenv("GIK_NO_PREP_QUAD", "1")
     from graphik_amd.solvers.riemannian_solver import BatchProblem
     robot, graph = make_graph(name)
     rng = np.random.RandomState(8)
@@ -738,6 +741,40 @@ def test_block_prepare_kernel_equals_wave_kernel(torch_cuda, monkeypatch, name, 
         out.append((tg.cpu().numpy(), Y.cpu().numpy(), K.cpu().numpy()))
     for a, b in zip(*out):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["planar10_limits_pi", "planar10_nolimits", "planar10_limits_halfpi"])
+def test_quad_prepare_kernel_against_wave_kernel(torch_cuda, monkeypatch, name):
+    """Four goals per wavefront (prep_quad_kernel, the default for graphs of at most 16 nodes) against one
+    (prep_wave_kernel, GIK_NO_PREP_QUAD read at attach): targets bit for bit (no inner product in them), MDS
+    column counts equal, initial points to round-off (the Jacobi threshold and the Householder reflectors sum in
+    another order; the K x K Jacobi runs the schedule of the wavefront's largest K) -- for batch sizes that leave
+    slots of the last wavefront empty, and the solves that start from either end on the same iteration."""
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    robot, graph = make_graph(name)
+    use_lim = not name.endswith("nolimits")
+    rng = np.random.RandomState(11)
+    lb_q, ub_q = robot.limits_arrays()
+    Tg = robot.fk_batch(lb_q + (ub_q - lb_q) * rng.rand(2051, robot.n))
+    quad = BatchProblem(graph, use_limits=use_lim)
+    monkeypatch.setenv("GIK_NO_PREP_QUAD", "1")
+    wave = BatchProblem(graph, use_limits=use_lim)
+    for B in (1, 2, 3, 5, 2051):
+        tq, Yq, Kq = [x.cpu().numpy() for x in quad.template.prepare(Tg[:B], return_K=True)]
+        tw, Yw, Kw = [x.cpu().numpy() for x in wave.template.prepare(Tg[:B], return_K=True)]
+        assert np.array_equal(tq, tw)
+        assert np.all(np.isfinite(Yq))
+        assert np.mean(Kq == Kw) >= 0.995        # (a count flips where an eigenvalue sits at the 1e-8 threshold)
+        assert np.abs(Yq - Yw).max() < 1e-10
+        Gq, Gw = Yq @ Yq.transpose(0, 2, 1), Yw @ Yw.transpose(0, 2, 1)
+        assert np.abs(Gq - Gw).max() < 1e-10 * np.abs(Gw).max()
+    rq = quad.template.solve(Yq[:256], tq[:256])
+    rw = wave.template.solve(Yw[:256], tw[:256])
+    # (below the round-off floor a redundant chain drifts along its solution set: the points are compared where
+    # that has not started, the answers by their cost)
+    assert np.mean(rq["iterations"].cpu().numpy() == rw["iterations"].cpu().numpy()) > 0.95
+    fq, fw = rq["f"].cpu().numpy(), rw["f"].cpu().numpy()
+    assert np.mean((fq < 1e-11) == (fw < 1e-11)) > 0.99 and np.mean(fq < 1e-11) > 0.9   # (tight limits: a few local minima)
 
 
 def test_lds_allowance_survives_later_templates(torch_cuda):
