@@ -529,7 +529,9 @@ class Bench:
         if prep_ms is not None:
             K_local = res["K"].double().cpu().numpy()
             pf = float(prepare_flops(N, K_local).sum())
-            prep_name = "prep_block_kernel" if info and info.get("prepare_is_block") else "prep_wave_kernel"
+            prep_name = ("prep_block_kernel" if info and info.get("prepare_is_block") else
+                         "prep_quad_kernel (four goals per wavefront)" if info and info.get("goals_per_wave") == 4 else
+                         "prep_wave_kernel")
             out["kernels"] = {"prepare_ms": prep_ms, "solve_ms": kernel_ms, "recover_ms": recover_ms,
                               "dominant": prep_name if prep_ms > kernel_ms else kernel_name}
             out["roofline_prepare"] = {

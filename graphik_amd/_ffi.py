@@ -41,7 +41,8 @@ class TemplateInfo(C.Structure):
                 ("n_slot_terms", C.c_int32), ("slots_per_thread", C.c_int32), ("waves_per_cu", C.c_int32),
                 ("n_cu", C.c_int32), ("lds_bytes", C.c_int32), ("clique_closed_form", C.c_int32),
                 ("anchored", C.c_int32), ("has_pipeline", C.c_int32), ("prepare_is_block", C.c_int32),
-                ("node_per_lane", C.c_int32), ("problems_per_wave", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("node_per_lane", C.c_int32), ("problems_per_wave", C.c_int32), ("goals_per_wave", C.c_int32),
+                ("reserved", C.c_int32 * 1)]
 
 
 SOLVER_TRUST_REGIONS, SOLVER_CONJUGATE_GRADIENT = 0, 1

@@ -135,13 +135,14 @@ __device__ inline void quad_jacobi(double *A, double *V, int S, int n, int sweep
   }
 }
 
-// The same for a matrix size known at compile time (the whole N x N matrix): the rounds are unrolled, every
+// The same for a matrix size N and a row stride S known at compile time (V must come in as the identity): the
+// rounds are unrolled, every
 // pair a constant, so a lane's accesses are its row (column) address plus an immediate offset -- each phase of a
 // round loads everything it needs, then computes, then stores: one LDS round trip per phase where the loop above
 // takes one per pair (the compiler has to assume that a pair's stores alias the next pair's loads).
-template <int N>
+template <int N, int S>
 __device__ inline void quad_jacobi_fixed(double *A, double *V, int sweeps, double2 *cs, int slot, int i) {
-  constexpr int S = N | 1, NE = N + (N & 1), NP = NE / 2;
+  constexpr int NE = N + (N & 1), NP = NE / 2;
   __builtin_amdgcn_wave_barrier();
   const bool row = i < N;
   double *Ar = A + i * S, *Vr = V + i * S, *Ac = A + i;   // this lane's row of A and V, column of A
@@ -273,10 +274,13 @@ __device__ inline int quad_count_eigs_above(double *A, int S, int N, double tau,
   return N - below;
 }
 
+// NT: the graph's node count where the kernel is compiled for it (13: the 10-link planar chains of BASELINE
+// configs[4] -- every loop bound and LDS offset a constant, the Jacobi rounds unrolled), 0: any N <= 16
+template <int NT>
 __global__ void __launch_bounds__(WAVE, 2) prep_quad_kernel(PrepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const PipeConst &pc = a.pc;
-  const int N = pc.N, K = pc.K, S = N | 1, D = K + 1;
+  const int N = NT ? NT : pc.N, K = pc.K, S = N | 1, D = K + 1;
   const int lane = threadIdx.x, slot = (lane >> 2) & 3, i = ((lane >> 4) << 2) | (lane & 3);
   const bool has = i < N;
   const int n_gd = 2 * pc.n_ee * pc.n_anchor + pc.n_gg, n_gd_pad = (n_gd + 1) & ~1;
@@ -381,7 +385,7 @@ __global__ void __launch_bounds__(WAVE, 2) prep_quad_kernel(PrepArgs a) {
 #ifdef GIK_DEV
     if (a.stop_phase == 4) continue;
 #endif
-    if (N == 13) quad_jacobi_fixed<13>(A, V, a.sweeps, cs, slot, i);   // (the 10-link chains of BASELINE configs[4])
+    if constexpr (NT > 0) quad_jacobi_fixed<NT, (NT | 1)>(A, V, a.sweeps, cs, slot, i);
     else quad_jacobi(A, V, S, N, a.sweeps, cs, slot, i);
 #ifdef GIK_DEV
     if (a.stop_phase == 5) continue;
@@ -444,7 +448,14 @@ __global__ void __launch_bounds__(WAVE, 2) prep_quad_kernel(PrepArgs a) {
     const int n2 = Kc > 1 ? Kc : 2;
     const int n2max = max(max(__builtin_amdgcn_readlane(n2, 0), __builtin_amdgcn_readlane(n2, 4)),
                           max(__builtin_amdgcn_readlane(n2, 8), __builtin_amdgcn_readlane(n2, 12)));
-    quad_jacobi(A, V, S, n2max, a.sweeps, cs, slot, i);
+    if constexpr (NT >= 8) {   // (the usual block sizes of a chain: K = 6..8)
+      if (n2max == 7) quad_jacobi_fixed<7, (NT | 1)>(A, V, a.sweeps, cs, slot, i);
+      else if (n2max == 8) quad_jacobi_fixed<8, (NT | 1)>(A, V, a.sweeps, cs, slot, i);
+      else if (n2max == 6) quad_jacobi_fixed<6, (NT | 1)>(A, V, a.sweeps, cs, slot, i);
+      else quad_jacobi(A, V, S, n2max, a.sweeps, cs, slot, i);
+    } else {
+      quad_jacobi(A, V, S, n2max, a.sweeps, cs, slot, i);
+    }
 #ifdef GIK_DEV
     if (a.stop_phase == 9) continue;
 #endif

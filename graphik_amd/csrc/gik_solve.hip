@@ -2262,7 +2262,8 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
       t->prep_quad_smem = prep_quad_lds_bytes(N, 2 * n_ee * d->n_anchor + pc.n_gg);
       int qocc = 0;
       if (t->prep_quad_smem <= 40 * 1024 &&
-          hipOccupancyMaxActiveBlocksPerMultiprocessor(&qocc, prep_quad_kernel, WAVE, t->prep_quad_smem) == hipSuccess &&
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&qocc, N == 13 ? prep_quad_kernel<13> : prep_quad_kernel<0>, WAVE,
+                                                       t->prep_quad_smem) == hipSuccess &&
           qocc >= 1) {
         t->prep_quad = true;
         if (const char *e = getenv("GIK_PREP_WAVES_PER_CU")) qocc = atoi(e);
@@ -2322,7 +2323,8 @@ int gik_prepare_batch_debug(const gik_template *t, const double *d_T_goal, int B
   } else if (t->prep_quad && !a.dbg_lb && !a.dbg_eig) {
     // (the diagnostics -- bounds and spectra of gik_prepare_batch_debug -- come from the one-goal-per-wavefront kernel)
     const int qgrid = std::min((B + QUAD_SLOTS - 1) / QUAD_SLOTS, t->n_cu * t->prep_quad_waves_per_cu);
-    hipLaunchKernelGGL(prep_quad_kernel, dim3(qgrid), dim3(WAVE), t->prep_quad_smem, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(t->N == 13 ? prep_quad_kernel<13> : prep_quad_kernel<0>, dim3(qgrid), dim3(WAVE), t->prep_quad_smem,
+                       (hipStream_t)stream, a);
   } else
     hipLaunchKernelGGL(prep_wave_kernel, dim3(grid), dim3(WAVE), t->prep_smem, (hipStream_t)stream,
                        a);
@@ -2749,6 +2751,7 @@ int gik_template_get_info(const gik_template *t, gik_template_info *info) {
   info->has_pipeline = t->has_pipe ? 1 : 0;
   info->prepare_is_block = t->prep_block ? 1 : 0;
   info->node_per_lane = t->is_npt ? t->npt_variant->NW : 0;
+  info->goals_per_wave = !t->has_pipe || t->prep_block ? 0 : (t->prep_quad ? gik::QUAD_SLOTS : 1);
   info->problems_per_wave = t->is_block ? 0 : ((t->quad_solve && !(t->dbg & (1 | 8192))) ? gik::QUAD_SLOTS : 1);
   if (t->is_npt) {
     info->waves_per_cu = t->npt_waves_per_cu;

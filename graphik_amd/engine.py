@@ -149,12 +149,17 @@ class Template:
                 self.n_goal_anchor, self.full_N = ad.n_goal_anchor, ad.full_N
                 _ffi.check(self.lib.gik_template_create_anchored(C.byref(d), C.byref(ad), C.byref(h)))
         self._h = h
-        info = _ffi.TemplateInfo()
-        _ffi.check(self.lib.gik_template_get_info(self._h, C.byref(info)))
-        self.info = {f: getattr(info, f) for f, _ in _ffi.TemplateInfo._fields_ if f != "reserved"}
+        self._read_info()
         deg = np.bincount(np.concatenate([self.term_i, self.term_j]), minlength=self.N).max()
         # compiled slot count of the wavefront variant the library chose (or the raw degree: workgroup / node-per-lane paths)
         self.maxdeg = int(self.info["max_terms_per_node"]) if not self.info["is_block"] else int(deg)
+
+    def _read_info(self):
+        """What the library decided for this handle (gik_template_get_info); read again after attach_pipeline,
+        which decides the prepare kernel."""
+        info = _ffi.TemplateInfo()
+        _ffi.check(self.lib.gik_template_get_info(self._h, C.byref(info)))
+        self.info = {f: getattr(info, f) for f, _ in _ffi.TemplateInfo._fields_ if f != "reserved"}
 
     @classmethod
     def from_matrices(cls, omega, psi_L=None, psi_U=None, k=3, use_limits=True, **kw):
@@ -301,6 +306,7 @@ class Template:
             _ffi.check(self.lib.gik_pipeline_attach(self._h, C.byref(d)))
         self.n_joints = int(d.n_joints)
         self.has_pipeline = True
+        self._read_info()
 
     def _poses(self, T_goal):
         T = _dev(T_goal, self.device)

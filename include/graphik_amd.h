@@ -200,7 +200,9 @@ typedef struct {
                                   node per lane, 1: two nodes per lane)                                   */
   int32_t problems_per_wave;   /* 4: planar graph (k = 2, <= 16 nodes, <= 6 terms per node) whose trust-region
                                   solves run four problems to a wavefront (rtr_quad_kernel); else 1 (0: block) */
-  int32_t reserved[2];
+  int32_t goals_per_wave;      /* prepare kernel: 4 = graph of at most 16 nodes, four goals to a wavefront
+                                  (prep_quad_kernel); 1 = one (prep_wave_kernel); 0 = workgroup per goal / no pipeline */
+  int32_t reserved[1];
 } gik_template_info;
 int gik_template_get_info(const gik_template *t, gik_template_info *info);
 

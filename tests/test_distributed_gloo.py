@@ -39,13 +39,21 @@ def test_shard_ranges_cover_batch():
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
 
 
+def _free_port():
+    """A rendezvous port nobody holds (a fixed one may still be in TIME_WAIT from the previous run)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_two_rank_gloo_gather(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = tmp_path / "full.npy"
     env = dict(os.environ, GIK_REPO=REPO, GIK_OUT=str(out), MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)]
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
     subprocess.run(cmd, check=True, env=env, timeout=300, capture_output=True)
     full = np.load(out)
     assert np.array_equal(full, np.arange(37.0)[:, None] * np.array([[1.0, 2.0, 3.0]]))
@@ -99,7 +107,7 @@ def test_bench_self_launches_ranks_and_gathers():
 def test_bench_refuses_a_wrong_world_size():
     """Started under a launcher whose world size is not --gpus, bench.py must say so (not assert)."""
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT="29541")
+               MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--dry-solve", "--gpus", "2"],
                        env=env, timeout=300, capture_output=True, text=True)
     assert r.returncode != 0 and "launcher started 1 rank" in (r.stderr + r.stdout)
@@ -161,8 +169,8 @@ def test_solve_batch_sharded_gathers_q_and_Y(tmp_path):
     assert one["q"].shape == (203, 7) and one["Y"].shape == (203, 18, 3)
     assert set(RESULT_STATS) <= set(one) and one["iterations"].dtype == np.int64
     assert result_row_bytes(7, 18, 3, with_Y=True) == 8 * (7 + len(RESULT_STATS) + 54)     # 560 B per problem
-    for world, port in ((2, 29541), (8, 29542)):
-        many = _run_sharded(tmp_path, world, port)
+    for world in (2, 8):
+        many = _run_sharded(tmp_path, world, _free_port())
         assert set(many) == set(one)
         for key in one:
             assert np.array_equal(one[key], many[key]), (world, key)

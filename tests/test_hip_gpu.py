@@ -759,12 +759,16 @@ def test_quad_prepare_kernel_against_wave_kernel(torch_cuda, monkeypatch, name):
     quad = BatchProblem(graph, use_limits=use_lim)
     monkeypatch.setenv("GIK_NO_PREP_QUAD", "1")
     wave = BatchProblem(graph, use_limits=use_lim)
+    assert quad.template.info["goals_per_wave"] == 4 and wave.template.info["goals_per_wave"] == 1
     for B in (1, 2, 3, 5, 2051):
         tq, Yq, Kq = [x.cpu().numpy() for x in quad.template.prepare(Tg[:B], return_K=True)]
         tw, Yw, Kw = [x.cpu().numpy() for x in wave.template.prepare(Tg[:B], return_K=True)]
         assert np.array_equal(tq, tw)
         assert np.all(np.isfinite(Yq))
-        assert np.mean(Kq == Kw) >= 0.995        # (a count flips where an eigenvalue sits at the 1e-8 threshold)
+        # MDS counts the eigenvalues above 1e-8 of a matrix whose small columns ARE of size 1e-8 (the square roots
+        # of Gram eigenvalues that are zero up to round-off, 1e-16): on 0.5-2.5 % of the goals the count depends on the
+        # last bit -- in the reference too -- and the columns it adds or drops weigh 1e-16 in the result below
+        assert np.mean(Kq == Kw) >= 0.95 and np.abs(Kq - Kw).max() <= 2
         assert np.abs(Yq - Yw).max() < 1e-10
         Gq, Gw = Yq @ Yq.transpose(0, 2, 1), Yw @ Yw.transpose(0, 2, 1)
         assert np.abs(Gq - Gw).max() < 1e-10 * np.abs(Gw).max()
