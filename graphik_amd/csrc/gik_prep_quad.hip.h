@@ -40,7 +40,7 @@ __host__ __device__ inline int prep_quad_goal_stride(int N) {
   return NS + ((24 - NS % 32) + 32) % 32;
 }
 __host__ __device__ inline size_t prep_quad_lds_bytes(int N, int n_gd) {
-  return sizeof(double) * ((size_t)12 * prep_quad_goal_stride(N) + 4 * (size_t)((n_gd + 1) & ~1) + 5 * 64) + sizeof(int) * 64;
+  return sizeof(double) * ((size_t)12 * prep_quad_goal_stride(N) + 4 * (size_t)((n_gd + 1) & ~1) + 6 * 64) + sizeof(int) * 64;
 }
 
 // does any lane of this lane's goal slot hold `c`?
@@ -79,7 +79,7 @@ __device__ inline bool quad_rotation(double app, double aqq, double apq, double 
 // Cyclic Jacobi (see jacobi_lds) on the leading n x n block of this goal's symmetric matrix A (row
 // stride S), V accumulates the eigenvectors as columns.  n is wave-uniform; a goal whose matrix is
 // non-zero in a smaller leading block only passes the larger n as well.  Lane `i` is row / column i
-// of its goal; cs: 8 (c, s) pairs of this goal.
+// of its goal; cs: (c, s) of this goal's pairs.
 __device__ inline void quad_jacobi(double *A, double *V, int S, int n, int sweeps, double2 *cs, int slot, int i) {
   const int ne = n + (n & 1), np = ne / 2;
   __builtin_amdgcn_wave_barrier();
@@ -135,97 +135,105 @@ __device__ inline void quad_jacobi(double *A, double *V, int S, int n, int sweep
   }
 }
 
-// The same for a matrix size N and a row stride S known at compile time (V must come in as the identity): the
-// rounds are unrolled, every
-// pair a constant, so a lane's accesses are its row (column) address plus an immediate offset -- each phase of a
-// round loads everything it needs, then computes, then stores: one LDS round trip per phase where the loop above
-// takes one per pair (the compiler has to assume that a pair's stores alias the next pair's loads).
+// The same for a matrix size N and a row stride S known at compile time (V must come in as the identity), with
+// the rows in REGISTERS.  What bounds the loop above is the LDS pipe -- one per CU, shared by all its wavefronts
+// -- at 49 KB per wavefront and round (every element of A read and written twice, of V once).  Here a lane keeps
+// row i of A and of V in registers for the whole decomposition; the rounds are unrolled, every pair a constant,
+// so the column rotations (A J, V J: a row's own entries) are plain register arithmetic.  The row rotations
+// (J^T A) need the partner's row: a round is
+//   write the own row to LDS -> the smaller index of each pair reads a_pp, a_qq, a_pq from that copy, forms the
+//   rotation and publishes (c, -s) / (c, +s) under both row indices -> every lane reads its own entry, the seven
+//   (c, s) of the round and the partner's row -> own' = c own -/+ s partner -> own' J in registers,
+// 19 KB of LDS traffic per wavefront and round.  A' = (J^T A) J where jacobi_lds forms J^T (A J): the same
+// matrix up to round-off.
 template <int N, int S>
 __device__ inline void quad_jacobi_fixed(double *A, double *V, int sweeps, double2 *cs, int slot, int i) {
   constexpr int NE = N + (N & 1), NP = NE / 2;
   __builtin_amdgcn_wave_barrier();
   const bool row = i < N;
-  double *Ar = A + i * S, *Vr = V + i * S, *Ac = A + i;   // this lane's row of A and V, column of A
-  // V is only ever touched row by row, and with constant column indices a row can stay in registers for the
-  // whole decomposition (it starts as the identity and is written out once, at the end): a third less LDS
-  // traffic per round -- the pipe all wavefronts of a CU share, and what bounds this loop
-  double vr[N];
+  double *Ar = A + i * S, *Vr = V + i * S;
+  double ar[N], vr[N];
 #pragma unroll
-  for (int j = 0; j < N; ++j) vr[j] = (i == j) ? 1.0 : 0.0;
-  double fro = 0.0;
-  if (row) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) fro = fma(Ar[j], Ar[j], fro);
+  for (int j = 0; j < N; ++j) {
+    ar[j] = row ? Ar[j] : 0.0;
+    vr[j] = (i == j) ? 1.0 : 0.0;
   }
+  cs[i] = make_double2(1.0, 0.0);
+  double fro = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) fro = fma(ar[j], ar[j], fro);
   const double thr = 1e-16 * sqrt(quad_sum(fro));
   const unsigned long long mine = 0x000F000F000F000Full << (4 * slot);
-  // the diagonal / off-diagonal entries lane m < NP needs for its rotation of round r: per-lane offsets
+  bool stale = false;            // (wave-uniform) the LDS copy of A is behind the registers
   for (int sw = 0; sw < sweeps; ++sw) {
     bool rotated = false;
 #pragma unroll
     for (int r = 0; r < NE - 1; ++r) {
-      bool sig = false;
-      if (i < NP) {
-        int p = 0, q = NE - 1;
+      // this lane's partner in round r (quad_rr_p / quad_rr_q seen from a row): index NE - 1 meets r, everybody
+      // else 2 r - i modulo NE - 1; a partner >= N is the bye of an odd N
+      int j = 2 * r - i;
+      j = j < 0 ? j + (NE - 1) : j;
+      j = j >= NE - 1 ? j - (NE - 1) : j;
+      j = (i == r) ? NE - 1 : j;
+      j = (i == NE - 1) ? r : j;
+      const bool paired = row && j < N;
+      if (stale) {
+        if (row) {
 #pragma unroll
-        for (int m = 0; m < NP; ++m) {
-          p = (i == m) ? quad_rr_p(NE, r, m) : p;
-          q = (i == m) ? quad_rr_q(NE, r, m) : q;
+          for (int c = 0; c < N; ++c) Ar[c] = ar[c];
         }
-        double c = 1.0, s = 0.0;
-        if (q < N) sig = quad_rotation(A[p * S + p], A[q * S + q], A[p * S + q], thr, c, s);
-        cs[i] = make_double2(c, s);
+        stale = false;
+      }
+      __builtin_amdgcn_wave_barrier();
+      bool sig = false;
+      if (paired && i < j) {
+        double c, s;
+        sig = quad_rotation(Ar[i], A[j * S + j], Ar[j], thr, c, s);
+        cs[i] = make_double2(c, -s);
+        cs[j] = make_double2(c, s);
+      } else if (row && !paired) {
+        cs[i] = make_double2(1.0, 0.0);
       }
       const unsigned long long anysig = __builtin_amdgcn_ballot_w64(sig);
-      if (anysig == 0ull) continue;
+      if (anysig == 0ull) continue;                        // nothing to rotate in this round, in any goal
       rotated = rotated || (anysig & mine) != 0ull;
       __builtin_amdgcn_wave_barrier();
+      const double2 own = cs[i];
+      const double *Pr = A + (paired ? j : i) * S;
+      double pr[N];
       double2 rc[NP];
 #pragma unroll
-      for (int m = 0; m < NP; ++m) rc[m] = cs[m];
-      if (row) {                                           // column phase: lane = row, A and V
-        double ap[NP], aq[NP];
+      for (int c = 0; c < N; ++c) pr[c] = Pr[c];
 #pragma unroll
-        for (int m = 0; m < NP; ++m)
-          if (quad_rr_q(NE, r, m) < N) {
-            ap[m] = Ar[quad_rr_p(NE, r, m)];
-            aq[m] = Ar[quad_rr_q(NE, r, m)];
-          }
+      for (int m = 0; m < NP; ++m)
+        if (quad_rr_q(NE, r, m) < N) rc[m] = cs[quad_rr_p(NE, r, m)];
+      // rows: p' = c p - s q, q' = c q + s p
 #pragma unroll
-        for (int m = 0; m < NP; ++m)
-          if (quad_rr_q(NE, r, m) < N) {
-            const double c = rc[m].x, s = rc[m].y;
-            Ar[quad_rr_p(NE, r, m)] = c * ap[m] - s * aq[m];
-            Ar[quad_rr_q(NE, r, m)] = s * ap[m] + c * aq[m];
-            const double vp = vr[quad_rr_p(NE, r, m)], vq = vr[quad_rr_q(NE, r, m)];
-            vr[quad_rr_p(NE, r, m)] = c * vp - s * vq;
-            vr[quad_rr_q(NE, r, m)] = s * vp + c * vq;
-          }
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (row) {                                           // row phase on A: lane = column
-        double ap[NP], aq[NP];
+      for (int c = 0; c < N; ++c) ar[c] = own.x * ar[c] + own.y * pr[c];
+      // columns of A' and of V
 #pragma unroll
-        for (int m = 0; m < NP; ++m)
-          if (quad_rr_q(NE, r, m) < N) {
-            ap[m] = Ac[quad_rr_p(NE, r, m) * S];
-            aq[m] = Ac[quad_rr_q(NE, r, m) * S];
-          }
-#pragma unroll
-        for (int m = 0; m < NP; ++m)
-          if (quad_rr_q(NE, r, m) < N) {
-            const double c = rc[m].x, s = rc[m].y;
-            Ac[quad_rr_p(NE, r, m) * S] = c * ap[m] - s * aq[m];
-            Ac[quad_rr_q(NE, r, m) * S] = s * ap[m] + c * aq[m];
-          }
-      }
-      __builtin_amdgcn_wave_barrier();
+      for (int m = 0; m < NP; ++m)
+        if (quad_rr_q(NE, r, m) < N) {
+          const int P = quad_rr_p(NE, r, m), Q = quad_rr_q(NE, r, m);   // (constants once the loops are unrolled)
+          const double c = rc[m].x, s = -rc[m].y;
+          const double ap = ar[P], aq = ar[Q];
+          ar[P] = c * ap - s * aq;
+          ar[Q] = s * ap + c * aq;
+          const double vp = vr[P], vq = vr[Q];
+          vr[P] = c * vp - s * vq;
+          vr[Q] = s * vp + c * vq;
+        }
+      stale = true;
     }
     if (__builtin_amdgcn_ballot_w64(rotated) == 0ull) break;
   }
+  __builtin_amdgcn_wave_barrier();
   if (row) {
 #pragma unroll
-    for (int j = 0; j < N; ++j) Vr[j] = vr[j];
+    for (int j = 0; j < N; ++j) {
+      Ar[j] = ar[j];
+      Vr[j] = vr[j];
+    }
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -233,6 +241,7 @@ __device__ inline void quad_jacobi_fixed(double *A, double *V, int sweeps, doubl
 // Number of eigenvalues > tau of this goal's symmetric N x N matrix A (destroyed): Householder
 // reduction to tridiagonal form + a Sturm count (see count_eigs_above_lds).  hv, hw: 16 doubles each.
 __device__ inline int quad_count_eigs_above(double *A, int S, int N, double tau, double *hv, double *hw, int i) {
+#pragma unroll 1
   for (int k = 0; k + 2 < N; ++k) {
     const bool mine = i > k && i < N;
     const double x = mine ? A[i * S + k] : 0.0;
@@ -293,8 +302,8 @@ __global__ void __launch_bounds__(WAVE, 2) prep_quad_kernel(PrepArgs a) {
   double *gd = smem + (size_t)12 * GS + (size_t)slot * n_gd_pad;
   double *vec = smem + (size_t)12 * GS + 4 * (size_t)n_gd_pad;
   double *ev = vec + slot * 16, *sg = vec + 64 + slot * 16, *hv = vec + 128 + slot * 16, *hw = vec + 192 + slot * 16;
-  double2 *cs = reinterpret_cast<double2 *>(vec + 256 + slot * 16);
-  int *rk = reinterpret_cast<int *>(vec + 320) + slot * 16;
+  double2 *cs = reinterpret_cast<double2 *>(vec + 256 + slot * 32);   // 16 (c, s) per goal: by pair, or by row
+  int *rk = reinterpret_cast<int *>(vec + 384) + slot * 16;
 
   const int groups = (a.B + QUAD_SLOTS - 1) / QUAD_SLOTS;
   for (int g4 = blockIdx.x; g4 < groups; g4 += gridDim.x) {
@@ -332,7 +341,8 @@ __global__ void __launch_bounds__(WAVE, 2) prep_quad_kernel(PrepArgs a) {
 #endif
     // ---- bound smoothing: ub = APSP(UPPER) (Floyd-Warshall; row m and column m do not change in step m), then
     //      lb[u][v] = max(0, max_{a,b} LOWER[a][b] - ub[u][a] - ub[b][v])   (see dgp.py)
-    for (int m = 0; m < N; ++m) {
+#pragma unroll 1
+    for (int m = 0; m < N; ++m) {                    // (rolled, like the Householder steps: no faster unrolled, 5 k instructions less)
       if (has) {
         const double uim = U[i * S + m];
         for (int j = 0; j < N; ++j) {
