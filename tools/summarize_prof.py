@@ -73,8 +73,12 @@ if "SQ_INSTS_VALU" in s:
         s["SQ_INSTS_SALU"] / hv, s["SQ_WAVE_CYCLES"] / hv, hv))
     # SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* count quad-cycles; per product and WAVEFRONT (a problem = 1, 2 or 8 of them)
     wpp = 8 if "rtr_block" in solve else (2 if "rtr_npt_kernel<1, 1, 2>" in solve or "rtr_npt_kernel<4, 1, 2>" in solve else 1)
-    print("wavefronts per problem %d: %.0f wave cycles per product and wavefront (batch average, co-resident problems included), "
-          "VALU-active %.0f" % (wpp, 4 * s["SQ_WAVE_CYCLES"] / hv / wpp, 4 * s["SQ_ACTIVE_INST_VALU"] / hv / wpp))
+    if "rtr_quad_kernel" in solve:
+        print("four problems per wavefront: %.0f wave cycles and %.0f VALU-active cycles per product of ONE problem "
+              "(a wavefront's tCG step serves up to four)" % (4 * s["SQ_WAVE_CYCLES"] / hv, 4 * s["SQ_ACTIVE_INST_VALU"] / hv))
+    else:
+        print("wavefronts per problem %d: %.0f wave cycles per product and wavefront (batch average, co-resident problems included), "
+              "VALU-active %.0f" % (wpp, 4 * s["SQ_WAVE_CYCLES"] / hv / wpp, 4 * s["SQ_ACTIVE_INST_VALU"] / hv / wpp))
     print("VALU active / wave cycles %.2f   LDS bank conflict / LDS active %.2f" % (
         s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"],
         s["SQ_LDS_BANK_CONFLICT"] / max(s.get("SQ_LDS_IDX_ACTIVE", 1), 1)))
