@@ -781,6 +781,41 @@ def test_quad_prepare_kernel_against_wave_kernel(torch_cuda, monkeypatch, name):
     assert np.mean((fq < 1e-11) == (fw < 1e-11)) > 0.99 and np.mean(fq < 1e-11) > 0.9   # (tight limits: a few local minima)
 
 
+@pytest.mark.parametrize("links", [4, 7, 13])
+def test_planar_chains_of_other_sizes_on_the_quad_kernels(torch_cuda, monkeypatch, links):
+    """Chains of 4 / 7 / 13 links (N = 7 / 10 / 16 nodes: the generic prep_quad_kernel<0>, and 16 = the largest
+    graph the four-per-wavefront kernels take) through the whole device pipeline, against the same pipeline on
+    the one-per-wavefront kernels: targets bit for bit, initial points to round-off, every goal reached by both,
+    iteration counts equal on nearly all goals, and every solution reproduces its goal position."""
+    from graphik_amd.robots import RobotPlanar
+    from graphik_amd.graphs import ProblemGraphPlanar
+    from graphik_amd.utils import list_to_variable_dict
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    lim = np.pi * np.ones(links)
+    robot = RobotPlanar({"link_lengths": list_to_variable_dict(0.5 + 0.1 * np.arange(links)),
+                         "theta": list_to_variable_dict(np.zeros(links)),
+                         "joint_limits_upper": list_to_variable_dict(lim),
+                         "joint_limits_lower": list_to_variable_dict(-lim), "num_joints": links})
+    graph = ProblemGraphPlanar(robot)
+    rng = np.random.RandomState(links)
+    Tg = robot.fk_batch(-lim + 2 * lim * rng.rand(301, links))
+    quad = BatchProblem(graph, use_limits=True)
+    assert quad.template.info["problems_per_wave"] == 4 and quad.template.info["goals_per_wave"] == 4
+    monkeypatch.setenv("GIK_NO_PREP_QUAD", "1")
+    wave = BatchProblem(graph, use_limits=True, params={"debug_flags": 8192})
+    assert wave.template.info["problems_per_wave"] == 1 and wave.template.info["goals_per_wave"] == 1
+    tq, Yq = [x.cpu().numpy() for x in quad.template.prepare(Tg)]
+    tw, Yw = [x.cpu().numpy() for x in wave.template.prepare(Tg)]
+    assert np.array_equal(tq, tw) and np.abs(Yq - Yw).max() < 1e-10
+    rq, rw = quad.template.ik(Tg), wave.template.ik(Tg)
+    fq, fw = rq["f"].cpu().numpy(), rw["f"].cpu().numpy()
+    assert np.mean((fq < 1e-11) == (fw < 1e-11)) > 0.99 and np.mean(fq < 1e-11) > 0.95
+    assert np.mean(rq["iterations"].cpu().numpy() == rw["iterations"].cpu().numpy()) > 0.95
+    ok = fq < 1e-11
+    assert np.all(rq["pos_err"].cpu().numpy()[ok] < 1e-5)
+    assert np.all(np.isfinite(rq["q"].cpu().numpy()))
+
+
 def test_lds_allowance_survives_later_templates(torch_cuda):
     """The dynamic-LDS allowance is a property of a kernel, not of a launch: a template that needs
     less (LWA4D on the workgroup kernels: 3 KB work matrix, 10 KB of solver state) created AFTER one
