@@ -2660,6 +2660,9 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     // 65536: slice 256 / 512 / 1024 / 2048 -> 501.5 / 500.9 / 510.6 / 514.0 ms and 118 k / 51 k / 19 k / 7.5 k
     // hand-overs; KUKA 8192: 145.5 / 147.7 / 161.6 ms -- short queues want the short slice.
     int wslice = (mig && !(a.dbg & 1024)) ? t->wave_slice_its : 0;
+    // (PMC, round 4, 65536 KUKA goals, tools/attic/c4_slice_traffic.sh: no slicing 202 MB per launch = 2.0 x the
+    // algorithmic bytes -- the floor of this kernel's 432 / 600-byte rows -- at 555 ms; slice 1024: 287 MB, 519 ms;
+    // 1536: 526 ms; 2048: 239 MB = 2.4 x, 537 ms.  Throughput decides: 1024.)
     if (wslice > 0 && t->wave_slice_auto && (long long)B > 8LL * grid)
       wslice = (int)std::min<long long>(4LL * wslice, (long long)wslice * B / (8LL * grid));
     // yield queue: a problem yields at most maxiter / slice + 1 times; the margin covers the waves that may be
