@@ -13,12 +13,14 @@
 // instruction stream serves four goals.  Same phases and -- per matrix element -- the same
 // operations in the same order as prep_wave_kernel (ProblemGraph.from_pose + graph_complete_edges,
 // graph_base.py:146-180, dgp.py:124-147; bound smoothing, dgp.py:192-231;
-// RiemannianSolver.generate_initialization, riemannian_solver.py:67-75), with two differences that
-// stay at round-off: the per-goal sums of the Jacobi threshold and of the Householder reflectors are
-// taken in another order, and the K x K Jacobi of linear_projection runs the round-robin schedule
-// of the LARGEST K among the wavefront's four goals (a goal with a smaller K sees extra pairs whose
-// off-diagonal entry is exactly zero: skipped).  Three matrices per goal instead of five (each
-// phase overwrites what the previous one no longer needs): 18 KB of LDS per wavefront at N = 13.
+// RiemannianSolver.generate_initialization, riemannian_solver.py:67-75), with differences that stay at
+// round-off: the per-goal sums of the Jacobi threshold and of the Householder reflectors are taken in
+// another order; the K x K Jacobi of linear_projection runs the round-robin schedule of the LARGEST K
+// among the wavefront's four goals (a goal with a smaller K sees extra pairs whose off-diagonal entry
+// is exactly zero: skipped); and where the matrix size is a compile-time constant a round forms
+// (J^T A) J from rows held in registers instead of J^T (A J) in LDS (quad_jacobi_fixed).  Three
+// matrices per goal instead of five (each phase overwrites what the previous one no longer needs):
+// 19.6 KB of LDS per wavefront at N = 13, eight wavefronts per CU.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -41,12 +43,6 @@ __host__ __device__ inline int prep_quad_goal_stride(int N) {
 }
 __host__ __device__ inline size_t prep_quad_lds_bytes(int N, int n_gd) {
   return sizeof(double) * ((size_t)12 * prep_quad_goal_stride(N) + 4 * (size_t)((n_gd + 1) & ~1) + 6 * 64) + sizeof(int) * 64;
-}
-
-// does any lane of this lane's goal slot hold `c`?
-__device__ inline bool quad_any_in_goal(bool c, int slot) {
-  const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
-  return (m & (0x000F000F000F000Full << (4 * slot))) != 0ull;
 }
 
 // round-robin (chess tournament) pair m of round r among ne (even) players, rr_pair without its divisions
