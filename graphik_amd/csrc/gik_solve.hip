@@ -864,7 +864,7 @@ static const NptVariant kNptVariants[] = {GIK_NPT_VARIANT(1, 1, 2), GIK_NPT_VARI
 //            fresh problem "accepts" its start point), gradient / Hessian constants / projector at
 //            the accepted points, stopping rules (:414-416), results of the finished slots.
 template <int DEG>
-__global__ void __launch_bounds__(WAVE, 2) rtr_quad_kernel(SolveArgs a) {
+__global__ void __launch_bounds__(WAVE, 3) rtr_quad_kernel(SolveArgs a) {
   using Ctx = QuadCtx<DEG>;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
