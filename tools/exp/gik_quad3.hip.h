@@ -4,8 +4,7 @@
 //
 // The throughput regime of the wavefront kernel (rtr_wave_kernel, one unknown per lane) is bound by
 // instruction issue: 162 VALU instructions per Hessian product, two waves per SIMD at 82 % of the
-// issue capacity (BASELINE configs[3]: 65536 KUKA goals, where 97 % of all products belong to the
-// 8 % of the goals that run to maxiter).  This kernel applies the layout of the planar kernel
+// issue capacity (BASELINE configs[3]: 65536 KUKA goals, 1.7 G Hessian products).  This kernel applies the layout of the planar kernel
 // (gik_quad.hip.h) to the 3-D arms: a problem is one 4-lane block column of the wave's four rows --
 // the 16 lanes v_mfma_f64_4x4x4 sums over -- and a lane owns whole NODES: node i and, for graphs of
 // more than 16 nodes (the 7-DOF arms have 18), node 16 + i.  Every solver scalar is a per-lane value,
