@@ -173,34 +173,61 @@ struct QuadCtx {
       const double it = 1.0 / (X00 + X11);
       u0 = 0.0; u1 = it; u2 = -it; u3 = 0.0;
     } else {
-      double A[4][5] = {{X00 + X00, X01, X01, 0.0, 0.0},
-                        {X01, X01 + X00, 0.0, X01, 1.0},
-                        {X01, 0.0, X00 + X11, X01, -1.0},
-                        {0.0, X01, X01, X11 + X11, 0.0}};
+      // The literal system of :107-110 (its [1][1] entry is X01 + X00) for the right-hand side [0, 1, -1, 0],
+      //   [2a  b    b    0 ] u0    0          a = X00, b = X01, c = X11
+      //   [b   a+b  0    b ] u1 =  1
+      //   [b   0    a+c  b ] u2   -1
+      //   [0   b    b    2c] u3    0
+      // solved by substitution instead of WaveCtx::proj_setup's elimination with pivoting (250 instructions, a
+      // tenth of this kernel's pass): rows 0 and 3 give u0 = -b s / 2a, u3 = -b s / 2c with s = u1 + u2, rows 1
+      // and 2 then u1 = (1 + k s) / (a + b), u2 = (k s - 1) / (a + c), k = b^2 (a + c) / (2 a c) <= (a + c) / 2
+      // (Cauchy-Schwarz), and their sum fixes s.  Same solution to round-off -- except where the literal entry
+      // a + b is small against a + c (b < 0): the substitution divides by it while the system as a whole stays
+      // well conditioned, so there (|a + b| < (a + c) / 20: a few per cent of the points) the elimination runs,
+      // for the whole wavefront under a uniform branch, and the slot concerned takes its result.
+      const double a = X00, b = X01, c = X11;
+      const double iab = 1.0 / (a + b), iac = 1.0 / (a + c), i2a = 0.5 / a, i2c = 0.5 / c;
+      const double k = b * b * (i2a + i2c);
+      const double s = (iab - iac) / (1.0 - k * (iab + iac));
+      u1 = (1.0 + k * s) * iab;
+      u2 = (k * s - 1.0) * iac;
+      u0 = -b * s * i2a;
+      u3 = -b * s * i2c;
+      const bool risky = !(fabs(a + b) >= 0.05 * (a + c));
+      if (quad_any(risky)) {
+        double A[4][5] = {{X00 + X00, X01, X01, 0.0, 0.0},
+                          {X01, X01 + X00, 0.0, X01, 1.0},
+                          {X01, 0.0, X00 + X11, X01, -1.0},
+                          {0.0, X01, X01, X11 + X11, 0.0}};
 #pragma unroll
-      for (int col = 0; col < 4; ++col) {
+        for (int col = 0; col < 4; ++col) {
 #pragma unroll
-        for (int r = col + 1; r < 4; ++r) {  // partial pivoting by compare-and-swap
-          const bool sw = fabs(A[r][col]) > fabs(A[col][col]);
+          for (int r = col + 1; r < 4; ++r) {  // partial pivoting by compare-and-swap
+            const bool sw = fabs(A[r][col]) > fabs(A[col][col]);
 #pragma unroll
-          for (int t = 0; t < 5; ++t) {
-            const double p = A[col][t], q = A[r][t];
-            A[col][t] = sw ? q : p;
-            A[r][t] = sw ? p : q;
+            for (int t = 0; t < 5; ++t) {
+              const double p = A[col][t], q = A[r][t];
+              A[col][t] = sw ? q : p;
+              A[r][t] = sw ? p : q;
+            }
+          }
+          const double ip = 1.0 / A[col][col];
+#pragma unroll
+          for (int r = col + 1; r < 4; ++r) {
+            const double fct = A[r][col] * ip;
+#pragma unroll
+            for (int t = col; t < 5; ++t) A[r][t] = fma(-fct, A[col][t], A[r][t]);
           }
         }
-        const double ip = 1.0 / A[col][col];
-#pragma unroll
-        for (int r = col + 1; r < 4; ++r) {
-          const double fct = A[r][col] * ip;
-#pragma unroll
-          for (int t = col; t < 5; ++t) A[r][t] = fma(-fct, A[col][t], A[r][t]);
-        }
+        const double e3 = A[3][4] / A[3][3];
+        const double e2 = (A[2][4] - A[2][3] * e3) / A[2][2];
+        const double e1 = (A[1][4] - A[1][2] * e2 - A[1][3] * e3) / A[1][1];
+        const double e0 = (A[0][4] - A[0][1] * e1 - A[0][2] * e2 - A[0][3] * e3) / A[0][0];
+        u0 = risky ? e0 : u0;
+        u1 = risky ? e1 : u1;
+        u2 = risky ? e2 : u2;
+        u3 = risky ? e3 : u3;
       }
-      u3 = A[3][4] / A[3][3];
-      u2 = (A[2][4] - A[2][3] * u3) / A[2][2];
-      u1 = (A[1][4] - A[1][2] * u2 - A[1][3] * u3) / A[1][1];
-      u0 = (A[0][4] - A[0][1] * u1 - A[0][2] * u2 - A[0][3] * u3) / A[0][0];
     }
     pk[0] = -hm * x1;
     pk[1] = hm * x0;
