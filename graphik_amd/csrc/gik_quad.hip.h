@@ -38,6 +38,42 @@ constexpr int QUAD_NODES = 16;   // nodes per problem
 __device__ inline double quad_sum(double v) { return mfma_blocksum(v); }
 __device__ inline bool quad_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 
+// The literal 4 x 4 system of the k = 2 projector (fixed_rank_psd_sym.py:107-110, rhs [0, 1, -1, 0]) by Gaussian
+// elimination with partial pivoting, as WaveCtx::proj_setup does it.  Not inlined: QuadCtx::proj_setup needs it
+// for a few per cent of the points only, and inlined its 20-entry tableau sets the register peak of the whole
+// kernel (spills of every wavefront instead of a call's save / restore in the rare case).
+__device__ __attribute__((noinline)) void planar_omega_by_elimination(double X00, double X01, double X11, double &u0,
+                                                                    double &u1, double &u2, double &u3) {
+  double A[4][5] = {{X00 + X00, X01, X01, 0.0, 0.0},
+                    {X01, X01 + X00, 0.0, X01, 1.0},
+                    {X01, 0.0, X00 + X11, X01, -1.0},
+                    {0.0, X01, X01, X11 + X11, 0.0}};
+#pragma unroll
+  for (int col = 0; col < 4; ++col) {
+#pragma unroll
+    for (int r = col + 1; r < 4; ++r) {  // partial pivoting by compare-and-swap
+      const bool sw = fabs(A[r][col]) > fabs(A[col][col]);
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const double p = A[col][t], q = A[r][t];
+        A[col][t] = sw ? q : p;
+        A[r][t] = sw ? p : q;
+      }
+    }
+    const double ip = 1.0 / A[col][col];
+#pragma unroll
+    for (int r = col + 1; r < 4; ++r) {
+      const double fct = A[r][col] * ip;
+#pragma unroll
+      for (int t = col; t < 5; ++t) A[r][t] = fma(-fct, A[col][t], A[r][t]);
+    }
+  }
+  u3 = A[3][4] / A[3][3];
+  u2 = (A[2][4] - A[2][3] * u3) / A[2][2];
+  u1 = (A[1][4] - A[1][2] * u2 - A[1][3] * u3) / A[1][1];
+  u0 = (A[0][4] - A[0][1] * u1 - A[0][2] * u2 - A[0][3] * u3) / A[0][0];
+}
+
 template <int DEG>
 struct QuadCtx {
   int lane, slot, node;
@@ -49,18 +85,19 @@ struct QuadCtx {
   // clamp, [11] no upper clamp (residual = clamp(target - d, lo, hi) with lo = -inf / 0, hi = +inf / 0: EQ (-inf, +inf),
   // LOWER (0, +inf), UPPER (-inf, 0), padding (0, 0) -- see WaveCtx::SlotRec), [31:16] term index
   uint32_t sl[DEG];
-  double tg[DEG];    // per problem: squared target distances
+  double *sh_tg;     // [DEG][64] per problem: squared target distances (LDS: only cost() and commit() read them)
   // per committed point: ys = 2 a (Y_i - Y_j) (a = 1 where the term is active, else 0), cc = 2 c
   double ys0[DEG], ys1[DEG], cc[DEG];
   double pk[2], pk2[2], G2;   // k = 2 projector (fixed_rank_psd_sym.py:107-113; Pm = 1)
 
   __host__ __device__ static constexpr size_t lds_bytes() {
-    return 2 * sizeof(double2) * QUAD_SLOTS * QUAD_NODES + sizeof(int) * 2 * QUAD_SLOTS;
+    return 2 * sizeof(double2) * QUAD_SLOTS * QUAD_NODES + sizeof(double) * DEG * WAVE + sizeof(int) * 2 * QUAD_SLOTS;
   }
 
   // g_meta: the wavefront kernel's slot table [DEG][64] (lane = 2 node + component)
-  __device__ inline void init(int lane_, int N, double2 *P, double2 *W, const uint32_t *g_meta) {
+  __device__ inline void init(int lane_, int N, double2 *P, double2 *W, double *TG, const uint32_t *g_meta) {
     lane = lane_;
+    sh_tg = TG;
     slot = (lane >> 2) & 3;
     node = ((lane >> 4) << 2) | (lane & 3);
     has_node = node < N;
@@ -75,7 +112,7 @@ struct QuadCtx {
       sl[s] = (uint32_t)((slot * QUAD_NODES + meta_j(m)) * sizeof(double2)) |
               ((kind == GIK_TERM_EQ || kind == GIK_TERM_UPPER) ? 0x400u : 0u) |
               ((kind == GIK_TERM_EQ || kind == GIK_TERM_LOWER) ? 0x800u : 0u) | ((uint32_t)meta_term(m) << 16);
-      tg[s] = 0.0;
+      sh_tg[s * WAVE + lane] = 0.0;
       ys0[s] = ys1[s] = cc[s] = 0.0;
     }
     pk[0] = pk[1] = pk2[0] = pk2[1] = G2 = 0.0;
@@ -87,7 +124,7 @@ struct QuadCtx {
   // per problem (divergent: only the lanes of the slot that starts problem b)
   __device__ inline void load_targets(const double *targets_b) {
 #pragma unroll
-    for (int s = 0; s < DEG; ++s) tg[s] = targets_b[sl[s] >> 16];
+    for (int s = 0; s < DEG; ++s) sh_tg[s * WAVE + lane] = targets_b[sl[s] >> 16];
   }
   __device__ inline const double2 &row(const double2 *base, int s) const {
     return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + (sl[s] & 0x3ffu));
@@ -112,7 +149,7 @@ struct QuadCtx {
       const double2 r = row(sh_P, s);
       const double a = x0 - r.x, b = x1 - r.y;
       const double d = fma(b, b, a * a);
-      const double cl = residual(s, tg[s] - d);
+      const double cl = residual(s, sh_tg[s * WAVE + lane] - d);
       f = fma(cl, cl, f);
     }
     return 0.5 * quad_sum(has_node ? f : 0.0);
@@ -128,7 +165,7 @@ struct QuadCtx {
       const double2 r = row(sh_P, s);
       const double a = o.x - r.x, b = o.y - r.y;
       const double d = fma(b, b, a * a);
-      const double cl = residual(s, tg[s] - d);
+      const double cl = residual(s, sh_tg[s * WAVE + lane] - d);
       // active: an equality always, a hinge iff its clamped residual is non-zero
       const bool act = ((sl[s] & 0xc00u) == 0xc00u) || (cl != 0.0);
       const double c = -cl;
@@ -195,34 +232,8 @@ struct QuadCtx {
       u3 = -b * s * i2c;
       const bool risky = !(fabs(a + b) >= 0.05 * (a + c));
       if (quad_any(risky)) {
-        double A[4][5] = {{X00 + X00, X01, X01, 0.0, 0.0},
-                          {X01, X01 + X00, 0.0, X01, 1.0},
-                          {X01, 0.0, X00 + X11, X01, -1.0},
-                          {0.0, X01, X01, X11 + X11, 0.0}};
-#pragma unroll
-        for (int col = 0; col < 4; ++col) {
-#pragma unroll
-          for (int r = col + 1; r < 4; ++r) {  // partial pivoting by compare-and-swap
-            const bool sw = fabs(A[r][col]) > fabs(A[col][col]);
-#pragma unroll
-            for (int t = 0; t < 5; ++t) {
-              const double p = A[col][t], q = A[r][t];
-              A[col][t] = sw ? q : p;
-              A[r][t] = sw ? p : q;
-            }
-          }
-          const double ip = 1.0 / A[col][col];
-#pragma unroll
-          for (int r = col + 1; r < 4; ++r) {
-            const double fct = A[r][col] * ip;
-#pragma unroll
-            for (int t = col; t < 5; ++t) A[r][t] = fma(-fct, A[col][t], A[r][t]);
-          }
-        }
-        const double e3 = A[3][4] / A[3][3];
-        const double e2 = (A[2][4] - A[2][3] * e3) / A[2][2];
-        const double e1 = (A[1][4] - A[1][2] * e2 - A[1][3] * e3) / A[1][1];
-        const double e0 = (A[0][4] - A[0][1] * e1 - A[0][2] * e2 - A[0][3] * e3) / A[0][0];
+        double e0, e1, e2, e3;
+        planar_omega_by_elimination(X00, X01, X11, e0, e1, e2, e3);
         u0 = risky ? e0 : u0;
         u1 = risky ? e1 : u1;
         u2 = risky ? e2 : u2;

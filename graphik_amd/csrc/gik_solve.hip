@@ -870,9 +870,10 @@ __global__ void __launch_bounds__(WAVE, 3) rtr_quad_kernel(SolveArgs a) {
   const int lane = threadIdx.x;
   double2 *sh_P = reinterpret_cast<double2 *>(smem);
   double2 *sh_W = sh_P + QUAD_SLOTS * QUAD_NODES;
-  int *sh_claim = reinterpret_cast<int *>(sh_W + QUAD_SLOTS * QUAD_NODES);
+  double *sh_tg = reinterpret_cast<double *>(sh_W + QUAD_SLOTS * QUAD_NODES);
+  int *sh_claim = reinterpret_cast<int *>(sh_tg + DEG * WAVE);
   Ctx cx;
-  cx.init(lane, a.N, sh_P, sh_W, a.slot_meta);
+  cx.init(lane, a.N, sh_P, sh_W, sh_tg, a.slot_meta);
   const Params &p = a.p;
   const int NK = a.N * 2;
   const bool lead = cx.node == 0;
