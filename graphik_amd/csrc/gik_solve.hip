@@ -1408,6 +1408,7 @@ struct gik_template {
   void (*quad_solve)(gik::SolveArgs) = nullptr;
   size_t quad_smem = 0;
   int quad_waves_per_cu = 8;
+  int quad_min_batch = 0;      // smallest batch that runs it (12 problems per CU; GIK_QUAD_MIN_BATCH)
   // device pre/post-processing (gik_pipeline_attach)
   bool has_pipe;
   gik::PipeConst pc;
@@ -2000,6 +2001,8 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     int qocc = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&qocc, (const void *)t->quad_solve, WAVE, t->quad_smem) == hipSuccess)
       t->quad_waves_per_cu = std::max(1, std::min(qocc, 32));
+    t->quad_min_batch = 12 * t->n_cu;
+    if (const char *e = getenv("GIK_QUAD_MIN_BATCH")) t->quad_min_batch = std::max(0, atoi(e));
   }
   if (ad) {
     // ---- fixed-anchor data ----
@@ -2710,7 +2713,10 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     if (mig || t->is_npt) HIP_OK(hipMemsetAsync(a.q_state, 0, (size_t)B * sizeof(SliceState), (hipStream_t)stream));
     if (ycap) HIP_OK(hipMemsetAsync(a.y_seq, 0, ycap * 4, (hipStream_t)stream));
   }
-  const bool quad = t->quad_solve && !(a.dbg & (1 | 8192));
+  // four planar problems per wavefront: from 12 problems per CU on (measured, planar-10, events around the call:
+  // 4..64 problems 158 against 95 us, 1024: 206 / 150, 4096: 259 / 282 -- below that every problem has a wavefront
+  // of its own anyway and the lone problem is faster there); debug_flags 16384: at any batch size
+  const bool quad = t->quad_solve && !(a.dbg & (1 | 8192)) && ((a.dbg & 16384) || B >= t->quad_min_batch);
   if (quad) {
     // a wavefront holds four problems: a quarter of the waves (at least one slot each), no slicing
     int qw = t->quad_waves_per_cu;

@@ -84,7 +84,8 @@ typedef struct {
                                 up (default: 16 nodes); 128 / 256 = older spellings of
                                 clique_closed_form = GIK_CLIQUE_OFF / GIK_CLIQUE_DENSE; 2048 = node-per-lane
                                 kernel with one wavefront per problem (two nodes per lane); 8192 = planar graphs: one
-                                problem per wavefront instead of four; 512 = neither round-robin
+                                problem per wavefront instead of four, 16384 = four at any batch size (default: from
+                                12 problems per CU on); 512 = neither round-robin
                                 slicing nor tail spreading on the wavefront kernel, 1024 = no slicing
                                 (scheduling measures of large batches, bit-neutral: tests compare) */
   /* which of the reference's two solvers gik_solve_batch runs (riemannian_solver.py:40-65):
@@ -199,7 +200,8 @@ typedef struct {
                                   512-thread workgroup kernel; the value is its wavefronts per problem (2: one
                                   node per lane, 1: two nodes per lane)                                   */
   int32_t problems_per_wave;   /* 4: planar graph (k = 2, <= 16 nodes, <= 6 terms per node) whose trust-region
-                                  solves run four problems to a wavefront (rtr_quad_kernel); else 1 (0: block) */
+                                  solves run four problems to a wavefront (rtr_quad_kernel) in batches of at
+                                  least 12 problems per CU; else 1 (0: block) */
   int32_t goals_per_wave;      /* prepare kernel: 4 = graph of at most 16 nodes, four goals to a wavefront
                                   (prep_quad_kernel); 1 = one (prep_wave_kernel); 0 = workgroup per goal / no pipeline */
   int32_t reserved[1];

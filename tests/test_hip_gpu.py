@@ -106,7 +106,7 @@ def test_trajectory_planar_identical_to_oracle(torch_cuda, name, per_wave):
     from graphik_amd.graphs.graph_planar import joint_variables_planar_batch
     d = load_golden(name)
     robot, graph = make_graph(name)
-    T = _template(d, debug_flags=0 if per_wave == 4 else 8192)
+    T = _template(d, debug_flags=16384 if per_wave == 4 else 8192)     # (16384: the four-problem kernel at any batch size)
     assert T.info["problems_per_wave"] == per_wave
     use_lim = bool(int(d["use_limits"]))
     r = T.solve(d["Y_init"], T.targets_from_D(d["D_goal"]), trace_cap=48)
@@ -799,7 +799,7 @@ def test_planar_chains_of_other_sizes_on_the_quad_kernels(torch_cuda, monkeypatc
     graph = ProblemGraphPlanar(robot)
     rng = np.random.RandomState(links)
     Tg = robot.fk_batch(-lim + 2 * lim * rng.rand(301, links))
-    quad = BatchProblem(graph, use_limits=True)
+    quad = BatchProblem(graph, use_limits=True, params={"debug_flags": 16384})      # (at any batch size)
     assert quad.template.info["problems_per_wave"] == 4 and quad.template.info["goals_per_wave"] == 4
     monkeypatch.setenv("GIK_NO_PREP_QUAD", "1")
     wave = BatchProblem(graph, use_limits=True, params={"debug_flags": 8192})
@@ -972,7 +972,9 @@ def test_quad_kernel_against_one_problem_per_wavefront(torch_cuda, name):
     from graphik_amd.engine import Template
     d = load_golden(name)
     kw = dict(k=2, use_limits=bool(int(d["use_limits"])))
-    Tq = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], **kw)
+    # (debug_flags 16384: the four-problem kernel at any batch size -- by default batches below 12 problems per CU
+    # run the one-problem kernel, which is faster there)
+    Tq = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"debug_flags": 16384}, **kw)
     Tw = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"debug_flags": 8192}, **kw)
     assert Tq.info["problems_per_wave"] == 4 and Tw.info["problems_per_wave"] == 1
     tg = Tq.targets_from_D(d["D_goal"])
@@ -1008,16 +1010,16 @@ def test_quad_kernel_stopping_rules(torch_cuda):
     kw = dict(k=2, use_limits=True)
     tg = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], **kw).targets_from_D(d["D_goal"])
     G = len(d["Y_init"])
-    for flags in (0, 8192):
+    for flags in (16384, 8192):
         T3 = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"maxiter": 3, "debug_flags": flags}, **kw)
         r = T3.solve(d["Y_init"], tg, trace_cap=8)
         assert np.all(r["iterations"].cpu().numpy() == 3) and np.all(r["stop"].cpu().numpy() == 1)
-        if flags == 0:
+        if flags == 16384:
             ref = r
         else:
             assert np.array_equal(r["inner_total"].cpu().numpy(), ref["inner_total"].cpu().numpy())
             assert np.allclose(r["x"].cpu().numpy(), ref["x"].cpu().numpy(), atol=1e-11)
-    T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], **kw)
+    T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"debug_flags": 16384}, **kw)
     Y0 = np.concatenate([d["Y_init"]] * 3)[:21].copy()
     tgb = np.concatenate([np.asarray(tg)] * 3)[:21]
     clean = T.solve(Y0, tgb)
@@ -1031,7 +1033,8 @@ def test_quad_kernel_stopping_rules(torch_cuda):
     assert np.array_equal(r["x"].cpu().numpy()[keep], clean["x"].cpu().numpy()[keep])
     # far below the round-off floor (mingradnorm = 0: every slot runs to maxiter = 40, steps rejected for dozens
     # of passes, radii shrinking to 1e-20): the masked loops must neither hang nor produce a NaN
-    Tm = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"maxiter": 40, "mingradnorm": 0.0}, **kw)
+    Tm = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"],
+                                params={"maxiter": 40, "mingradnorm": 0.0, "debug_flags": 16384}, **kw)
     rm = Tm.solve(Y0, tgb)
     assert np.all(rm["iterations"].cpu().numpy() == 40) and np.all(rm["stop"].cpu().numpy() == 1)
     assert float(rm["f"].max()) < 1e-20 and np.all(np.isfinite(rm["x"].cpu().numpy()))

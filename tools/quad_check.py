@@ -14,7 +14,7 @@ def load_golden(name):
 
 def templates(d):
     kw = dict(k=2, use_limits=bool(int(d["use_limits"])))
-    Tq = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"debug_flags": 0}, **kw)
+    Tq = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"debug_flags": 16384}, **kw)
     Tw = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], params={"debug_flags": 8192}, **kw)
     assert Tq.info["problems_per_wave"] == 4 and Tw.info["problems_per_wave"] == 1, (Tq.info, Tw.info)
     return Tq, Tw
