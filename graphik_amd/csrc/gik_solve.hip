@@ -1086,6 +1086,47 @@ __global__ void __launch_bounds__(WAVE, 3) rtr_quad_kernel(SolveArgs a) {
   }
 }
 
+// The device functions of QuadCtx one call at a time (known-answer tests: gik_cost / gik_grad / gik_hess / gik_proj
+// on a template created with debug_flags 16384), four problems per wavefront like the solve kernel
+template <int DEG>
+__global__ void __launch_bounds__(WAVE) kat_quad_kernel(KatArgs a) {
+  using Ctx = QuadCtx<DEG>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  double2 *sh_P = reinterpret_cast<double2 *>(smem);
+  double2 *sh_W = sh_P + QUAD_SLOTS * QUAD_NODES;
+  double *sh_tg = reinterpret_cast<double *>(sh_W + QUAD_SLOTS * QUAD_NODES);
+  Ctx cx;
+  cx.init(lane, a.N, sh_P, sh_W, sh_tg, a.slot_meta);
+  const int b_raw = (int)blockIdx.x * QUAD_SLOTS + cx.slot, NK = a.N * 2;
+  const bool valid = b_raw < a.B;
+  const int b = valid ? b_raw : a.B - 1;
+  if (a.targets) cx.load_targets(a.targets + (size_t)b * a.T);
+  const double2 y = cx.has_node ? *reinterpret_cast<const double2 *>(a.Y + (size_t)b * NK + 2 * cx.node) : make_double2(0.0, 0.0);
+  const double2 w = (a.W && cx.has_node) ? *reinterpret_cast<const double2 *>(a.W + (size_t)b * NK + 2 * cx.node)
+                                         : make_double2(0.0, 0.0);
+  const double f = cx.cost(y.x, y.y);        // (also publishes the rows of y)
+  if (a.mode == 0) {
+    if (valid && cx.node == 0) a.out[b] = f;
+    return;
+  }
+  double r0 = 0.0, r1 = 0.0;
+  if (a.mode == 1 || a.mode == 4) {
+    cx.commit(r0, r1);
+    if (a.mode == 4 && valid && cx.node == 0) a.out_f[b] = f;
+  } else if (a.mode == 2) {
+    double g0, g1;
+    cx.commit(g0, g1);
+    cx.ehess(w.x, w.y, r0, r1);
+  } else {
+    cx.proj_setup(y.x, y.y, a.planar_proj_exact);
+    const double o = quad_sum(fma(cx.pk[1], w.y, cx.pk[0] * w.x));     // Omega (Pm = 1)
+    r0 = fma(-cx.pk2[0], o, w.x);
+    r1 = fma(-cx.pk2[1], o, w.y);
+  }
+  if (valid && cx.has_node) *reinterpret_cast<double2 *>(a.out + (size_t)b * NK + 2 * cx.node) = make_double2(r0, r1);
+}
+
 // ------------------------------------------------------------------------------------------
 // developer micro-benchmark: per-component cycle cost of one wavefront.  Only in the -DGIK_DEV
 // build (graphik_amd/build.py --dev -> lib/exp/libgraphik_amd_dev.so); the shipped library has
@@ -2474,7 +2515,10 @@ static int launch_kat(const gik_template *t, int mode, const double *d_Y, const 
     HIP_OK(hipGetLastError());
     return 0;
   }
-  if (t->is_npt) {
+  if (t->quad_solve && (t->dbg & 16384) && !(t->dbg & (1 | 8192))) {
+    hipLaunchKernelGGL(kat_quad_kernel<6>, dim3((B + QUAD_SLOTS - 1) / QUAD_SLOTS), dim3(WAVE), t->quad_smem,
+                       (hipStream_t)stream, a);
+  } else if (t->is_npt) {
     a.nt = t->nt;
     hipLaunchKernelGGL(t->npt_variant->kat, dim3(B), dim3(WAVE * t->npt_variant->NW), t->npt_smem, (hipStream_t)stream, a);
   } else if (t->is_block) {

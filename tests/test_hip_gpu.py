@@ -29,43 +29,47 @@ def _template(d, **params):
 # ---- kernel-level known answers (costgrd twins + proj): 1e-12 relative ----------------------
 @pytest.mark.parametrize("name", SCENARIOS)
 def test_cost_grad_hess_proj_known_answers(torch_cuda, name):
+    """(Planar scenarios twice: the one-problem-per-wavefront context and, with debug_flags 16384, the
+    four-problems-per-wavefront context QuadCtx through kat_quad_kernel -- six points: two wavefronts, the second
+    half empty.)"""
     from oracle import c_oracle as co
     d = load_golden(name)
-    T = _template(d)
-    key = "lim" if int(d["use_limits"]) else "nolim"
-    tg = T.targets_from_D(d["D_goal"][0])
-    Y, W = d["kat_Y"], d["kat_W"]
-    assert rel_err(T.cost(Y, tg).cpu().numpy(), d[f"kat_{key}_loop_cost"]) < 1e-12
-    assert rel_err(T.grad(Y, tg).cpu().numpy(), d[f"kat_{key}_loop_grad"]) < 1e-12
-    assert rel_err(T.hess(Y, W, tg).cpu().numpy(), d[f"kat_{key}_loop_hess"]) < 1e-12
-    assert rel_err(T.proj(Y, W).cpu().numpy(), d["kat_proj"]) < 1e-12
-    # and against the oracle on fresh random points, including points near a solution where the
-    # hinge terms switch on and off
-    rng = np.random.RandomState(5)
-    om, pL, pU, D = d["omega"], d["psi_L"], d["psi_U"], d["D_goal"][0]
-    use_lim = bool(int(d["use_limits"]))
-    inds = co.limit_inds(om, pL, pU) if use_lim else np.nonzero(np.triu(om))
-    Ys = np.stack([d["Y_sol"][0] + s * rng.randn(*d["Y_sol"][0].shape)
-                   for s in (0.0, 1e-6, 1e-3, 0.05, 0.3, 1.0)])
-    Ws = rng.randn(*Ys.shape)
-    g = T.grad(Ys, tg).cpu().numpy()
-    h = T.hess(Ys, Ws, tg).cpu().numpy()
-    c = T.cost(Ys, tg).cpu().numpy()
-    # fused twin (lcost_and_grad / jcost_and_grad): one pass, bit-identical to the separate calls
-    cf, gf = T.cost_and_grad(Ys, tg)
-    assert np.array_equal(cf.cpu().numpy(), c) and np.array_equal(gf.cpu().numpy(), g)
-    for m in range(len(Ys)):
-        if use_lim:
-            rc = co.lcost(Ys[m], D, om, pL, pU, inds)
-            rg = co.lgrad(Ys[m], D, om, pL, pU, inds)
-            rh = co.lhess(Ys[m], Ws[m], D, om, pL, pU, inds)
-        else:
-            rc, rg, rh = co.jcost(Ys[m], D, inds), co.jgrad(Ys[m], D, inds), co.jhess(Ys[m], Ws[m], D, inds)
-        # near a solution the residuals D - d cancel to ~1e-8 of their operands, so the
-        # achievable accuracy is eps*|D| per residual: absolute floors on top of 1e-12 relative
-        assert abs(c[m] - rc) <= 1e-12 * abs(rc) + 1e-14 * np.sqrt(abs(rc))
-        assert np.abs(g[m] - rg).max() <= 1e-12 * np.abs(rg).max() + 1e-13
-        assert np.abs(h[m] - rh).max() <= 1e-12 * np.abs(rh).max() + 1e-13
+    templates = [_template(d)] + ([_template(d, debug_flags=16384)] if int(d["dim"]) == 2 else [])
+    for T in templates:
+        key = "lim" if int(d["use_limits"]) else "nolim"
+        tg = T.targets_from_D(d["D_goal"][0])
+        Y, W = d["kat_Y"], d["kat_W"]
+        assert rel_err(T.cost(Y, tg).cpu().numpy(), d[f"kat_{key}_loop_cost"]) < 1e-12
+        assert rel_err(T.grad(Y, tg).cpu().numpy(), d[f"kat_{key}_loop_grad"]) < 1e-12
+        assert rel_err(T.hess(Y, W, tg).cpu().numpy(), d[f"kat_{key}_loop_hess"]) < 1e-12
+        assert rel_err(T.proj(Y, W).cpu().numpy(), d["kat_proj"]) < 1e-12
+        # and against the oracle on fresh random points, including points near a solution where the
+        # hinge terms switch on and off
+        rng = np.random.RandomState(5)
+        om, pL, pU, D = d["omega"], d["psi_L"], d["psi_U"], d["D_goal"][0]
+        use_lim = bool(int(d["use_limits"]))
+        inds = co.limit_inds(om, pL, pU) if use_lim else np.nonzero(np.triu(om))
+        Ys = np.stack([d["Y_sol"][0] + s * rng.randn(*d["Y_sol"][0].shape)
+                       for s in (0.0, 1e-6, 1e-3, 0.05, 0.3, 1.0)])
+        Ws = rng.randn(*Ys.shape)
+        g = T.grad(Ys, tg).cpu().numpy()
+        h = T.hess(Ys, Ws, tg).cpu().numpy()
+        c = T.cost(Ys, tg).cpu().numpy()
+        # fused twin (lcost_and_grad / jcost_and_grad): one pass, bit-identical to the separate calls
+        cf, gf = T.cost_and_grad(Ys, tg)
+        assert np.array_equal(cf.cpu().numpy(), c) and np.array_equal(gf.cpu().numpy(), g)
+        for m in range(len(Ys)):
+            if use_lim:
+                rc = co.lcost(Ys[m], D, om, pL, pU, inds)
+                rg = co.lgrad(Ys[m], D, om, pL, pU, inds)
+                rh = co.lhess(Ys[m], Ws[m], D, om, pL, pU, inds)
+            else:
+                rc, rg, rh = co.jcost(Ys[m], D, inds), co.jgrad(Ys[m], D, inds), co.jhess(Ys[m], Ws[m], D, inds)
+            # near a solution the residuals D - d cancel to ~1e-8 of their operands, so the
+            # achievable accuracy is eps*|D| per residual: absolute floors on top of 1e-12 relative
+            assert abs(c[m] - rc) <= 1e-12 * abs(rc) + 1e-14 * np.sqrt(abs(rc))
+            assert np.abs(g[m] - rg).max() <= 1e-12 * np.abs(rg).max() + 1e-13
+            assert np.abs(h[m] - rh).max() <= 1e-12 * np.abs(rh).max() + 1e-13
 
 
 @pytest.mark.parametrize("name", ["lwa4d", "planar10_limits_halfpi"])
