@@ -32,6 +32,12 @@
 namespace gik {
 
 constexpr int PREPQ_MAXN = QUAD_NODES;
+// The small per-goal arrays -- ev, sg, hv, hw (16 doubles each), the rotations (c, s) (16 double2) and the ranks (16
+// ints) -- form ONE block of 104 doubles per goal slot.  104 = 8 mod 32: what the four goals of a half-wave read at
+// the same index (broadcast reads, most of the traffic to these arrays; for the rotations a ds_read_b128) falls into
+// four different bank groups.  Until round 5 every array had a slot stride of 16 or 32 doubles: the four goals' (c, s)
+// sat on the SAME banks (every read of a rotation 4-way conflicted), the others two by two.
+constexpr int PREPQ_VEC_STRIDE = 104;
 
 // doubles between the matrices of neighbouring goals: N rows of odd stride S = N | 1, padded to 24 mod 32 doubles
 // (48 of the 64 four-byte banks).  With the 16 rows of a goal at odd stride the rows a half-wave touches in the
@@ -42,7 +48,7 @@ __host__ __device__ inline int prep_quad_goal_stride(int N) {
   return NS + ((24 - NS % 32) + 32) % 32;
 }
 __host__ __device__ inline size_t prep_quad_lds_bytes(int N, int n_gd) {
-  return sizeof(double) * ((size_t)12 * prep_quad_goal_stride(N) + 4 * (size_t)((n_gd + 1) & ~1) + 6 * 64) + sizeof(int) * 64;
+  return sizeof(double) * ((size_t)12 * prep_quad_goal_stride(N) + 4 * (size_t)((n_gd + 1) & ~1) + 4 * PREPQ_VEC_STRIDE);
 }
 
 // round-robin (chess tournament) pair m of round r among ne (even) players, rr_pair without its divisions
@@ -143,16 +149,18 @@ __device__ inline void quad_jacobi(double *A, double *V, int S, int n, int sweep
 // 19 KB of LDS traffic per wavefront and round.  A' = (J^T A) J where jacobi_lds forms J^T (A J): the same
 // matrix up to round-off.
 template <int N, int S>
-__device__ inline void quad_jacobi_fixed(double *A, double *V, int sweeps, double2 *cs, int slot, int i) {
+__device__ inline void quad_jacobi_fixed(double *A, double *V, int sweeps, double2 *cs, int slot, int i) {   // (i by value: made opaque per round)
   constexpr int NE = N + (N & 1), NP = NE / 2;
   __builtin_amdgcn_wave_barrier();
-  const bool row = i < N;
-  double *Ar = A + i * S, *Vr = V + i * S;
   double ar[N], vr[N];
+  {
+    const bool row = i < N;
+    const double *Ar = A + i * S;
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    ar[j] = row ? Ar[j] : 0.0;
-    vr[j] = (i == j) ? 1.0 : 0.0;
+    for (int j = 0; j < N; ++j) {
+      ar[j] = row ? Ar[j] : 0.0;
+      vr[j] = (i == j) ? 1.0 : 0.0;
+    }
   }
   cs[i] = make_double2(1.0, 0.0);
   double fro = 0.0;
@@ -167,6 +175,12 @@ __device__ inline void quad_jacobi_fixed(double *A, double *V, int sweeps, doubl
     for (int r = 0; r < NE - 1; ++r) {
       // this lane's partner in round r (quad_rr_p / quad_rr_q seen from a row): index NE - 1 meets r, everybody
       // else 2 r - i modulo NE - 1; a partner >= N is the bye of an odd N
+      // (the row index goes through an empty asm per round: what a round derives from it -- partner, flags, LDS
+      //  addresses -- is then recomputed there, a dozen integer instructions, instead of being hoisted out of the
+      //  sweep loop for all 13 rounds at once and spilled: round 4's build kept 123 VGPRs in scratch)
+      asm volatile("" : "+v"(i));
+      const bool row = i < N;
+      double *Ar = A + i * S;
       int j = 2 * r - i;
       j = j < 0 ? j + (NE - 1) : j;
       j = j >= NE - 1 ? j - (NE - 1) : j;
@@ -224,7 +238,8 @@ __device__ inline void quad_jacobi_fixed(double *A, double *V, int sweeps, doubl
     if (__builtin_amdgcn_ballot_w64(rotated) == 0ull) break;
   }
   __builtin_amdgcn_wave_barrier();
-  if (row) {
+  if (i < N) {
+    double *Ar = A + i * S, *Vr = V + i * S;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       Ar[j] = ar[j];
@@ -286,8 +301,8 @@ __global__ void __launch_bounds__(WAVE, 2) prep_quad_kernel(PrepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const PipeConst &pc = a.pc;
   const int N = NT ? NT : pc.N, K = pc.K, S = N | 1, D = K + 1;
-  const int lane = threadIdx.x, slot = (lane >> 2) & 3, i = ((lane >> 4) << 2) | (lane & 3);
-  const bool has = i < N;
+  const int lane = threadIdx.x, slot = (lane >> 2) & 3;
+  int i = ((lane >> 4) << 2) | (lane & 3);
   const int n_gd = 2 * pc.n_ee * pc.n_anchor + pc.n_gg, n_gd_pad = (n_gd + 1) & ~1;
   // three matrices per goal: M0 = upper bounds -> eigenvectors; M1 = lower-bound table -> lower bounds
   // -> D_rand -> MDS factor X; M2 = work matrix
@@ -296,13 +311,15 @@ __global__ void __launch_bounds__(WAVE, 2) prep_quad_kernel(PrepArgs a) {
   double *M1 = smem + (size_t)(4 + slot) * GS;
   double *M2 = smem + (size_t)(8 + slot) * GS;
   double *gd = smem + (size_t)12 * GS + (size_t)slot * n_gd_pad;
-  double *vec = smem + (size_t)12 * GS + 4 * (size_t)n_gd_pad;
-  double *ev = vec + slot * 16, *sg = vec + 64 + slot * 16, *hv = vec + 128 + slot * 16, *hw = vec + 192 + slot * 16;
-  double2 *cs = reinterpret_cast<double2 *>(vec + 256 + slot * 32);   // 16 (c, s) per goal: by pair, or by row
-  int *rk = reinterpret_cast<int *>(vec + 384) + slot * 16;
+  double *vec = smem + (size_t)12 * GS + 4 * (size_t)n_gd_pad + (size_t)slot * PREPQ_VEC_STRIDE;
+  double *ev = vec, *sg = vec + 16, *hv = vec + 32, *hw = vec + 48;
+  double2 *cs = reinterpret_cast<double2 *>(vec + 64);                // 16 (c, s) per goal: by pair, or by row
+  int *rk = reinterpret_cast<int *>(vec + 96);
 
   const int groups = (a.B + QUAD_SLOTS - 1) / QUAD_SLOTS;
   for (int g4 = blockIdx.x; g4 < groups; g4 += gridDim.x) {
+    asm volatile("" : "+v"(i));     // (row-derived addresses are recomputed per group, not kept across the loop: see quad_jacobi_fixed)
+    const bool has = i < N;
     const int b_raw = g4 * QUAD_SLOTS + slot;
     const bool valid = b_raw < a.B;
     const int b = valid ? b_raw : a.B - 1;           // (an empty slot of the last group repeats the last goal, unstored)

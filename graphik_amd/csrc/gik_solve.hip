@@ -2611,13 +2611,20 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   // that no other call holds.  The lock covers the hand-out only: waiting for a slot's previous user, growing
   // its workspace (hipEventSynchronize / hipFree / hipMalloc) and the launch happen outside it, on a slot
   // marked in_use.
+  // (hipEventQuery is not allowed while a stream captures: a capturing caller skips the warm-slot test)
+  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+  if (stream && hipStreamIsCapturing((hipStream_t)stream, &cap_status) != hipSuccess) {
+    (void)hipGetLastError();
+    cap_status = hipStreamCaptureStatusNone;
+  }
+  const bool capturing = cap_status != hipStreamCaptureStatusNone;
   auto take = [&](auto &slots, unsigned &next, unsigned n) -> int {
     for (;;) {
       {
         std::lock_guard<std::mutex> lock(mt->call_mutex);
         const unsigned last = (next + n - 1) % n;
         auto &ls = slots[last];
-        if (!ls.in_use && ls.done && (!ls.pending || hipEventQuery(ls.done) == hipSuccess)) {
+        if (!ls.in_use && ls.done && (!ls.pending || (!capturing && hipEventQuery(ls.done) == hipSuccess))) {
           ls.pending = false;
           ls.in_use = true;
           return (int)last;
@@ -2783,9 +2790,16 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
                        dim3(grid), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
   }
   HIP_OK(hipGetLastError());
+  // The slots go back "pending" only behind an event that really covers this launch.  If a record fails,
+  // nothing guards the counter / workspace against the next caller: wait for the kernel here and hand the
+  // slots back idle instead.
+  const hipError_t e_cs = hipEventRecord(cs.done, (hipStream_t)stream);
+  const hipError_t e_sw = sw ? hipEventRecord(sw->done, (hipStream_t)stream) : hipSuccess;
+  if (e_cs != hipSuccess || e_sw != hipSuccess) {
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    return fail(std::string("hipEventRecord failed after the launch: ") + hipGetErrorString(e_cs != hipSuccess ? e_cs : e_sw));
+  }
   release.launched = true;
-  HIP_OK(hipEventRecord(cs.done, (hipStream_t)stream));
-  if (sw) HIP_OK(hipEventRecord(sw->done, (hipStream_t)stream));
   return 0;
 }
 

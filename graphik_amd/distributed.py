@@ -43,10 +43,18 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# what the last gather_rows() call of this process did: {"collective", "sent_bytes", "recv_bytes"} --
+# a rank other than `dst` must receive nothing (ONE gather; tests assert recv_bytes == 0)
+LAST_GATHER = {}
+
+
 def gather_rows(local, total, dst=0):
     """Gather row-sharded tensors (shards as produced by shard_range) onto rank `dst`.
-    Returns the [total, ...] tensor on dst, None elsewhere.  Single collective."""
+    Returns the [total, ...] tensor on dst, None elsewhere.  Single collective: `gather` to `dst`
+    (ncclGather-equivalent under RCCL: every peer sends its rows over its own xGMI link to dst and
+    receives nothing); `all_gather` only if the backend refuses `gather`."""
     if not dist.is_initialized():
+        LAST_GATHER.update(collective="none", sent_bytes=0, recv_bytes=0)
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [shard_range(total, r, world) for r in range(world)]
@@ -54,12 +62,18 @@ def gather_rows(local, total, dst=0):
     pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    if dist.get_backend() == "nccl":
-        # all_gather is RCCL's best-supported path; the payload is a few hundred bytes/problem
+    collective = "gather"
+    try:
+        dist.gather(pad, bufs, dst=dst)
+    except (RuntimeError, NotImplementedError) as e:          # a backend build without gather
+        if "gather" not in str(e).lower() and "not supported" not in str(e).lower():
+            raise
+        collective = "all_gather"
         bufs = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(bufs, pad)
-    else:
-        dist.gather(pad, bufs, dst=dst)
+    row_bytes = pad.element_size() * int(np.prod(pad.shape))
+    LAST_GATHER.update(collective=collective, sent_bytes=row_bytes if rank != dst or collective != "gather" else 0,
+                       recv_bytes=0 if bufs is None else row_bytes * (world - 1))
     if rank != dst:
         return None
     return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
@@ -72,17 +86,25 @@ RESULT_STATS = ("pos_err", "rot_err", "f", "gradnorm", "iterations", "inner_tota
 
 def pack_results(res, with_Y=False, device=None):
     """One float64 row per problem of this rank's shard: q [n] | RESULT_STATS | (Y [N*k]).
-    `res`: dict of tensors or arrays with keys "q", RESULT_STATS and (with_Y) "x"."""
+    `res`: dict of tensors or arrays with keys "q", RESULT_STATS and (with_Y) "x".  A shard of zero
+    rows packs to [0, width] (the widths come from the trailing dimensions, never from -1)."""
     def col(v):
         t = v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))
         t = t.to(torch.float64)
         if device is not None:
             t = t.to(device)
-        return t.reshape(t.shape[0], -1)
+        return t.reshape(t.shape[0], int(np.prod(t.shape[1:])) if t.dim() > 1 else 1)
     cols = [col(res["q"])] + [col(res[k]) for k in RESULT_STATS]
     if with_Y:
         cols.append(col(res["x"]))
     return torch.cat(cols, dim=1).contiguous()
+
+
+def empty_results(n, N=0, k=0, with_Y=False, device=None):
+    """The [0, width] table of a rank whose shard is empty (more ranks than goals): it still enters
+    the gather, it never touches the device solve."""
+    width = n + len(RESULT_STATS) + (N * k if with_Y else 0)
+    return torch.zeros((0, width), dtype=torch.float64, device=device)
 
 
 def unpack_results(table, n, with_Y=False, point_shape=None):
@@ -106,34 +128,38 @@ def result_row_bytes(n, N=0, k=0, with_Y=False):
 
 def solve_batch_sharded(graph, T_goals, use_limits=True, params=None, with_Y=False, dst=0, solve_fn=None):
     """solve_batch over all ranks of the process group (one rank per GPU; without a process group:
-    this process alone).  EVERY rank passes the full batch T_goals [B, ...] (128 B per goal); rank r
-    solves rows shard_range(B, r, world) and the results are gathered on rank `dst` in ONE collective
-    of result_row_bytes() per problem.  Returns (q [B,n], Y [B,N,k] or None, info) on `dst`,
-    (None, None, None) elsewhere.  `solve_fn(T_local) -> dict` replaces the device solve (tests of
-    the rank / shard / gather logic on machines without a GPU)."""
-    T = np.asarray(T_goals, dtype=float)
-    B = T.shape[0]
+    this process alone).  EVERY rank passes the full batch T_goals [B, ...] (128 B per goal; anything
+    with len() and row slicing -- an ndarray, a memory map, a lazy sequence: a rank only ever
+    materialises ITS rows); rank r solves rows shard_range(B, r, world) and the results are gathered
+    on rank `dst` in ONE collective of result_row_bytes() per problem.  Returns (q [B,n], Y [B,N,k]
+    or None, info) on `dst`, (None, None, None) elsewhere.  A rank whose shard is empty (B < world)
+    skips the solve and contributes zero rows.  `solve_fn(T_local) -> dict` replaces the device solve
+    (tests of the rank / shard / gather logic on machines without a GPU)."""
+    B = len(T_goals)
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     lo, hi = shard_range(B, rank, world)
+    T = np.asarray(T_goals[lo:hi], dtype=float)           # this rank's rows only
     n = graph.robot.n
     N, k = graph.number_of_nodes(), graph.dim
-    on_gpu = not (dist.is_initialized() and dist.get_backend() != "nccl") and torch.cuda.is_available()
-    if solve_fn is not None:
-        res = solve_fn(T[lo:hi])
-        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    cpu_group = dist.is_initialized() and dist.get_backend() != "nccl"
+    on_gpu = not cpu_group and torch.cuda.is_available()
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    if hi == lo:
+        table = empty_results(n, N, k, with_Y=with_Y, device=dev)
+    elif solve_fn is not None:
+        table = pack_results(solve_fn(T), with_Y=with_Y, device=dev)
     else:
         from .solvers.riemannian_solver import _problem_for, solve_batch
         prob = _problem_for(graph, use_limits, params, None)
-        dev = prob.template.device
+        dev = torch.device("cpu") if cpu_group else prob.template.device
         if prob.device_pipeline:          # prepare -> solve -> recover on the device, results stay there
-            res = prob.template.ik(torch.from_numpy(np.ascontiguousarray(T[lo:hi])).to(dev))
+            res = prob.template.ik(torch.from_numpy(np.ascontiguousarray(T)).to(prob.template.device))
         else:
-            q, Y, info = solve_batch(graph, T[lo:hi], use_limits=use_limits, params=params)
+            q, Y, info = solve_batch(graph, T, use_limits=use_limits, params=params)
             res = dict(info, q=q, x=Y, f=info["f(x)"], inner_total=info["inner_iterations"],
                        n_accept=np.zeros(len(q)), inner_executed=info["inner_iterations"])
-        if dist.is_initialized() and dist.get_backend() != "nccl":
-            dev = torch.device("cpu")
-    table = gather_rows(pack_results(res, with_Y=with_Y, device=dev), B, dst=dst)
+        table = pack_results(res, with_Y=with_Y, device=dev)
+    table = gather_rows(table, B, dst=dst)
     if rank != dst:
         return None, None, None
     return unpack_results(table, n, with_Y=with_Y, point_shape=(N, k))

@@ -27,7 +27,11 @@ _STOP_REASONS = {0: "Terminated - min grad norm reached", 1: "Terminated - max i
 BetaTypes = ["FletcherReeves", "PolakRibiere", "HestenesStiefel", "HagerZhang"]
 
 
-_closure_templates = {}
+# Templates behind the create_cost / create_cost_limits closures: least-recently-used, bounded like
+# _PROBLEM_CACHE (a Template owns device tables and a HIP handle), keyed by the device as well, and
+# emptied by clear_problem_cache()
+_closure_templates = collections.OrderedDict()
+_CLOSURE_TEMPLATES_MAX = 8
 
 
 def _cost_closures(D_goal, omega, psi_L, psi_U, use_limits):
@@ -42,10 +46,15 @@ def _cost_closures(D_goal, omega, psi_L, psi_U, use_limits):
     def tpl(Y):
         k = int(np.asarray(Y).shape[-1])
         if state.get("k") != k:
-            key = (k, use_limits, omega.tobytes(), None if psi_L is None else psi_L.tobytes(),
+            dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+            key = (dev, k, use_limits, omega.tobytes(), None if psi_L is None else psi_L.tobytes(),
                    None if psi_U is None else psi_U.tobytes())
             if key not in _closure_templates:
                 _closure_templates[key] = Template.from_matrices(omega, psi_L, psi_U, k=k, use_limits=use_limits)
+                while len(_closure_templates) > _CLOSURE_TEMPLATES_MAX:
+                    _closure_templates.popitem(last=False)
+            else:
+                _closure_templates.move_to_end(key)
             state["k"], state["T"] = k, _closure_templates[key]
             state["tg"] = state["T"].targets_from_D(D_goal)
         return state["T"], state["tg"]
@@ -540,6 +549,7 @@ def _problem_for(graph, use_limits=True, params=None, device=None):
 
 def clear_problem_cache():
     _PROBLEM_CACHE.clear()
+    _closure_templates.clear()
 
 
 def solve_batch(graph, T_goals, use_limits=True, params=None, device=None, Y_init=None):

@@ -136,11 +136,34 @@ def solve_fn(T_local):            # deterministic stand-in for the device solve,
 
 q, Y, info = gd.solve_batch_sharded(graph, T, with_Y=True, solve_fn=solve_fn)
 q2, Y2, info2 = gd.solve_batch_sharded(graph, T, with_Y=False, solve_fn=solve_fn)
+# SURVEY 8(e): ONE gather to dst -- a rank other than dst sends its rows and receives NOTHING
+if world > 1:
+    assert gd.LAST_GATHER["collective"] == "gather", gd.LAST_GATHER
+    if rank != 0:
+        assert gd.LAST_GATHER["recv_bytes"] == 0 and gd.LAST_GATHER["sent_bytes"] > 0, gd.LAST_GATHER
+    else:
+        assert gd.LAST_GATHER["recv_bytes"] > 0
+# fewer goals than ranks: the ranks with an empty shard skip the solve and still enter the gather
+calls = []
+def counting(T_local):
+    calls.append(len(T_local))
+    return solve_fn(T_local)
+class RowsOnly:                       # a batch that refuses to be materialised as a whole
+    def __init__(self, a): self.a = a
+    def __len__(self): return len(self.a)
+    def __getitem__(self, s):
+        assert isinstance(s, slice) and (s.stop - s.start) <= -(-len(self.a) // world), "rank read other ranks' goals"
+        return self.a[s]
+q3, Y3, info3 = gd.solve_batch_sharded(graph, RowsOnly(T[:3]), with_Y=True, solve_fn=counting)
+lo3, hi3 = gd.shard_range(3, rank, world)
+assert calls == ([hi3 - lo3] if hi3 > lo3 else []), (rank, calls)
+q0, Y0, info0 = gd.solve_batch_sharded(graph, T[:0], with_Y=True, solve_fn=counting)      # an empty batch
 if rank == 0:
     assert Y2 is None and np.array_equal(q, q2)
-    np.savez(os.environ["GIK_OUT"], q=q, Y=Y, **info)
+    assert q0.shape == (0, n) and Y0.shape == (0, N, k)
+    np.savez(os.environ["GIK_OUT"], q=q, Y=Y, q3=q3, Y3=Y3, it3=info3["iterations"], **info)
 else:
-    assert q is None and Y is None and info is None and q2 is None
+    assert q is None and Y is None and info is None and q2 is None and q3 is None
 '''
 
 
@@ -168,6 +191,8 @@ def test_solve_batch_sharded_gathers_q_and_Y(tmp_path):
     one = _run_sharded(tmp_path, 1, 0)
     assert one["q"].shape == (203, 7) and one["Y"].shape == (203, 18, 3)
     assert set(RESULT_STATS) <= set(one) and one["iterations"].dtype == np.int64
+    # (B = 3 < world = 8: ADVICE r4 -- empty shards used to raise before the gather and hang the others)
+    assert one["q3"].shape == (3, 7) and np.array_equal(one["q3"], one["q"][:3]) and np.array_equal(one["Y3"], one["Y"][:3])
     assert result_row_bytes(7, 18, 3, with_Y=True) == 8 * (7 + len(RESULT_STATS) + 54)     # 560 B per problem
     for world in (2, 8):
         many = _run_sharded(tmp_path, world, _free_port())
