@@ -6,11 +6,18 @@
 // 34 k instructions per goal, 3.6 of the 5.1 ms of BASELINE configs[4].  Here a wavefront holds FOUR
 // goals in the lane layout of the planar solve kernel (gik_quad.hip.h):
 //
-//   lane l = 16 r + 4 b + i   ->   goal slot b (0..3), matrix row n = 4 r + i (0..15)
+//   lane l = 16 b + n   ->   goal slot b (0..3), matrix row n (0..15)
 //
-// so a lane owns a ROW of its goal's N x N matrices (LDS, odd row stride: the 16 rows of a goal fall
-// into different banks), per-goal reductions are two v_mfma_f64_4x4x4 (quad_sum), and one
-// instruction stream serves four goals.  Same phases and -- per matrix element -- the same
+// (round 5; until then the lane map of the planar SOLVE kernel, l = 16 r + 4 b + i, so that per-goal sums were
+// two MFMAs: with it a 16-lane store group held four rows of all four goals and a 32-lane load group eight
+// rows of all four, and no placement of the goals makes both conflict-free -- measured SQ_LDS_BANK_CONFLICT /
+// SQ_LDS_IDX_ACTIVE = 0.50 with the LDS pipe 69 % busy, the kernel's bound.  With a goal per 16-lane DPP row a
+// store group is ONE goal's 16 rows -- odd row stride: 16 different bank pairs -- and a load group two goals'
+// rows, disjoint when the goals lie 16 doubles apart modulo 32 (prep_quad_goal_stride); per-goal sums are four
+// row_ror steps (goal_sum), which the kernel needs ~40 times per group of goals.)
+//
+// so a lane owns a ROW of its goal's N x N matrices (LDS, odd row stride), and one instruction stream serves
+// four goals.  Same phases and -- per matrix element -- the same
 // operations in the same order as prep_wave_kernel (ProblemGraph.from_pose + graph_complete_edges,
 // graph_base.py:146-180, dgp.py:124-147; bound smoothing, dgp.py:192-231;
 // RiemannianSolver.generate_initialization, riemannian_solver.py:67-75), with differences that stay at
@@ -39,13 +46,40 @@ constexpr int PREPQ_MAXN = QUAD_NODES;
 // sat on the SAME banks (every read of a rotation 4-way conflicted), the others two by two.
 constexpr int PREPQ_VEC_STRIDE = 104;
 
-// doubles between the matrices of neighbouring goals: N rows of odd stride S = N | 1, padded to 24 mod 32 doubles
-// (48 of the 64 four-byte banks).  With the 16 rows of a goal at odd stride the rows a half-wave touches in the
-// column phase (lane = row, one column) fall into 8 distinct bank pairs per goal, and the four goals' sets -- like
-// the four 16-bank runs of the row phase (lane = column) -- are disjoint exactly when the goals sit 16 banks apart.
+// sum over the 16 lanes of a goal (a DPP row); every lane gets the total, bit-identical in all 16 (each level adds
+// two partial sums that are equal in the lanes exchanging them)
+__device__ inline double goal_sum(double v) {
+  v += dpp_f64<0x128>(v);   // row_ror:8
+  v += dpp_f64<0x124>(v);   // row_ror:4
+  v += dpp_f64<0x122>(v);   // row_ror:2
+  v += dpp_f64<0x121>(v);   // row_ror:1
+  return v;
+}
+
+// LDS byte address of a pointer into the kernel's dynamic shared memory
+__device__ inline unsigned lds_addr(const void *p) {
+  return (unsigned)(__UINTPTR_TYPE__)(const __attribute__((address_space(3))) void *)p;
+}
+// N consecutive doubles from LDS as N ds_read_b64.  Left to itself the compiler pairs neighbouring loads into
+// ds_read2_b64, which the LDS serves at HALF the rate of ds_read_b64 (MI355X_MICROARCH.md, LDS table: 8 cycles per
+// 16 bytes and lane against 2 x 2) -- and this kernel is bound by the LDS pipe.
+template <int N>
+__device__ inline void lds_read_row(double (&v)[N], const double *row) {
+  const unsigned a = lds_addr(row);
+#pragma unroll
+  for (int c = 0; c < N; ++c) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[c]) : "v"(a), "n"(8 * c) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < N; ++c) asm volatile("" : "+v"(v[c]));      // (uses stay behind the wait)
+}
+
+// doubles between the matrices of neighbouring goals: N rows of odd stride S = N | 1, padded to 16 mod 32 doubles.
+// A ds_read_b64 is served per half-wave = the rows of TWO goals.  Lane = row, one column: goal 0 touches the bank
+// pairs S * {0..N-1} (mod 32; distinct: S is odd), goal 1 the set S * {0..N-1} + 16 = S * {16..16+N-1} -- disjoint.
+// Lane = column, one row: two runs of N <= 16 consecutive doubles, 16 apart -- disjoint as well.
 __host__ __device__ inline int prep_quad_goal_stride(int N) {
   const int NS = N * (N | 1);
-  return NS + ((24 - NS % 32) + 32) % 32;
+  return NS + ((16 - NS % 32) + 32) % 32;
 }
 __host__ __device__ inline size_t prep_quad_lds_bytes(int N, int n_gd) {
   return sizeof(double) * ((size_t)12 * prep_quad_goal_stride(N) + 4 * (size_t)((n_gd + 1) & ~1) + 4 * PREPQ_VEC_STRIDE);
@@ -88,8 +122,8 @@ __device__ inline void quad_jacobi(double *A, double *V, int S, int n, int sweep
   double fro = 0.0;
   if (i < n)
     for (int j = 0; j < n; ++j) fro = fma(A[i * S + j], A[i * S + j], fro);
-  const double thr = 1e-16 * sqrt(quad_sum(fro));
-  const unsigned long long mine = 0x000F000F000F000Full << (4 * slot);
+  const double thr = 1e-16 * sqrt(goal_sum(fro));
+  const unsigned long long mine = 0xFFFFull << (16 * slot);
   for (int sw = 0; sw < sweeps; ++sw) {
     bool rotated = false;
     for (int r = 0; r < ne - 1; ++r) {
@@ -144,8 +178,9 @@ __device__ inline void quad_jacobi(double *A, double *V, int S, int n, int sweep
 // so the column rotations (A J, V J: a row's own entries) are plain register arithmetic.  The row rotations
 // (J^T A) need the partner's row: a round is
 //   write the own row to LDS -> the smaller index of each pair reads a_pp, a_qq, a_pq from that copy, forms the
-//   rotation and publishes (c, -s) / (c, +s) under both row indices -> every lane reads its own entry, the seven
-//   (c, s) of the round and the partner's row -> own' = c own -/+ s partner -> own' J in registers,
+//   rotation and publishes (c, -s) under its row index -> every lane reads its pair's entry (the larger index flips
+//   the sign of s), the seven (c, s) of the round and the partner's row (plain ds_read_b64: lds_read_row) ->
+//   own' = c own -/+ s partner -> own' J in registers,
 // 19 KB of LDS traffic per wavefront and round.  A' = (J^T A) J where jacobi_lds forms J^T (A J): the same
 // matrix up to round-off.
 template <int N, int S>
@@ -166,8 +201,8 @@ __device__ inline void quad_jacobi_fixed(double *A, double *V, int sweeps, doubl
   double fro = 0.0;
 #pragma unroll
   for (int j = 0; j < N; ++j) fro = fma(ar[j], ar[j], fro);
-  const double thr = 1e-16 * sqrt(quad_sum(fro));
-  const unsigned long long mine = 0x000F000F000F000Full << (4 * slot);
+  const double thr = 1e-16 * sqrt(goal_sum(fro));
+  const unsigned long long mine = 0xFFFFull << (16 * slot);
   bool stale = false;            // (wave-uniform) the LDS copy of A is behind the registers
   for (int sw = 0; sw < sweeps; ++sw) {
     bool rotated = false;
@@ -196,24 +231,22 @@ __device__ inline void quad_jacobi_fixed(double *A, double *V, int sweeps, doubl
       }
       __builtin_amdgcn_wave_barrier();
       bool sig = false;
-      if (paired && i < j) {
+      if (paired && i < j) {          // the smaller index of a pair forms the rotation and publishes (c, -s) under its row index
         double c, s;
         sig = quad_rotation(Ar[i], A[j * S + j], Ar[j], thr, c, s);
         cs[i] = make_double2(c, -s);
-        cs[j] = make_double2(c, s);
-      } else if (row && !paired) {
-        cs[i] = make_double2(1.0, 0.0);
       }
       const unsigned long long anysig = __builtin_amdgcn_ballot_w64(sig);
       if (anysig == 0ull) continue;                        // nothing to rotate in this round, in any goal
       rotated = rotated || (anysig & mine) != 0ull;
       __builtin_amdgcn_wave_barrier();
-      const double2 own = cs[i];
-      const double *Pr = A + (paired ? j : i) * S;
+      // own rotation: the pair's entry, s with the other sign for the larger index; a bye multiplies by (1, 0)
+      double2 own = cs[paired ? (i < j ? i : j) : i];
+      own.y = (i < j) ? own.y : -own.y;
+      if (!paired) own = make_double2(1.0, 0.0);
       double pr[N];
       double2 rc[NP];
-#pragma unroll
-      for (int c = 0; c < N; ++c) pr[c] = Pr[c];
+      lds_read_row<N>(pr, A + (paired ? j : i) * S);
 #pragma unroll
       for (int m = 0; m < NP; ++m)
         if (quad_rr_q(NE, r, m) < N) rc[m] = cs[quad_rr_p(NE, r, m)];
@@ -257,7 +290,7 @@ __device__ inline int quad_count_eigs_above(double *A, int S, int N, double tau,
     const bool mine = i > k && i < N;
     const double x = mine ? A[i * S + k] : 0.0;
     const double x0 = A[(k + 1) * S + k];
-    const double s0 = quad_sum(x * x), s1 = quad_sum((mine && i > k + 1) ? x * x : 0.0);
+    const double s0 = goal_sum(x * x), s1 = goal_sum((mine && i > k + 1) ? x * x : 0.0);
     const bool go = s1 != 0.0;                       // else: column already tridiagonal (goal-uniform)
     const double alpha = x0 > 0.0 ? -sqrt(s0) : sqrt(s0);
     const double vj = mine ? (i == k + 1 ? x - alpha : x) : 0.0;
@@ -269,7 +302,7 @@ __device__ inline int quad_count_eigs_above(double *A, int S, int N, double tau,
     if (mine)
       for (int c = k + 1; c < N; ++c) pj = fma(A[i * S + c], hv[c], pj);
     pj *= beta;
-    const double Kc = 0.5 * beta * quad_sum(vj * pj);
+    const double Kc = 0.5 * beta * goal_sum(vj * pj);
     const double wj = pj - Kc * vj;
     hw[i] = mine ? wj : 0.0;
     __builtin_amdgcn_wave_barrier();
@@ -301,8 +334,8 @@ __global__ void __launch_bounds__(WAVE, 2) prep_quad_kernel(PrepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const PipeConst &pc = a.pc;
   const int N = NT ? NT : pc.N, K = pc.K, S = N | 1, D = K + 1;
-  const int lane = threadIdx.x, slot = (lane >> 2) & 3;
-  int i = ((lane >> 4) << 2) | (lane & 3);
+  const int lane = threadIdx.x, slot = lane >> 4;
+  int i = lane & 15;
   const int n_gd = 2 * pc.n_ee * pc.n_anchor + pc.n_gg, n_gd_pad = (n_gd + 1) & ~1;
   // three matrices per goal: M0 = upper bounds -> eigenvectors; M1 = lower-bound table -> lower bounds
   // -> D_rand -> MDS factor X; M2 = work matrix
@@ -469,8 +502,8 @@ __global__ void __launch_bounds__(WAVE, 2) prep_quad_kernel(PrepArgs a) {
 #endif
     // the largest block among the four goals sets the schedule (wave-uniform)
     const int n2 = Kc > 1 ? Kc : 2;
-    const int n2max = max(max(__builtin_amdgcn_readlane(n2, 0), __builtin_amdgcn_readlane(n2, 4)),
-                          max(__builtin_amdgcn_readlane(n2, 8), __builtin_amdgcn_readlane(n2, 12)));
+    const int n2max = max(max(__builtin_amdgcn_readlane(n2, 0), __builtin_amdgcn_readlane(n2, 16)),
+                          max(__builtin_amdgcn_readlane(n2, 32), __builtin_amdgcn_readlane(n2, 48)));
     if constexpr (NT >= 8) {   // (the usual block sizes of a chain: K = 6..8)
       if (n2max == 7) quad_jacobi_fixed<7, (NT | 1)>(A, V, a.sweeps, cs, slot, i);
       else if (n2max == 8) quad_jacobi_fixed<8, (NT | 1)>(A, V, a.sweeps, cs, slot, i);
