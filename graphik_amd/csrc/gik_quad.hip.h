@@ -42,8 +42,12 @@ __device__ inline bool quad_any(bool c) { return __builtin_amdgcn_ballot_w64(c) 
 // elimination with partial pivoting, as WaveCtx::proj_setup does it.  Not inlined: QuadCtx::proj_setup needs it
 // for a few per cent of the points only, and inlined its 20-entry tableau sets the register peak of the whole
 // kernel (spills of every wavefront instead of a call's save / restore in the rare case).
-__device__ __attribute__((noinline)) void planar_omega_by_elimination(double X00, double X01, double X11, double &u0,
-                                                                    double &u1, double &u2, double &u3) {
+// (round 5: the solution comes back by value -- four doubles in registers; by reference it was a 32-byte stack frame,
+//  i.e. scratch memory for every wavefront of the kernel.)
+struct Omega4 {
+  double u0, u1, u2, u3;
+};
+__device__ __attribute__((noinline)) Omega4 planar_omega_by_elimination(double X00, double X01, double X11) {
   double A[4][5] = {{X00 + X00, X01, X01, 0.0, 0.0},
                     {X01, X01 + X00, 0.0, X01, 1.0},
                     {X01, 0.0, X00 + X11, X01, -1.0},
@@ -68,10 +72,12 @@ __device__ __attribute__((noinline)) void planar_omega_by_elimination(double X00
       for (int t = col; t < 5; ++t) A[r][t] = fma(-fct, A[col][t], A[r][t]);
     }
   }
-  u3 = A[3][4] / A[3][3];
-  u2 = (A[2][4] - A[2][3] * u3) / A[2][2];
-  u1 = (A[1][4] - A[1][2] * u2 - A[1][3] * u3) / A[1][1];
-  u0 = (A[0][4] - A[0][1] * u1 - A[0][2] * u2 - A[0][3] * u3) / A[0][0];
+  Omega4 o;
+  o.u3 = A[3][4] / A[3][3];
+  o.u2 = (A[2][4] - A[2][3] * o.u3) / A[2][2];
+  o.u1 = (A[1][4] - A[1][2] * o.u2 - A[1][3] * o.u3) / A[1][1];
+  o.u0 = (A[0][4] - A[0][1] * o.u1 - A[0][2] * o.u2 - A[0][3] * o.u3) / A[0][0];
+  return o;
 }
 
 template <int DEG>
@@ -88,6 +94,7 @@ struct QuadCtx {
   double *sh_tg;     // [DEG][64] per problem: squared target distances (LDS: only cost() and commit() read them)
   // per committed point: ys = 2 a (Y_i - Y_j) (a = 1 where the term is active, else 0), cc = 2 c
   double ys0[DEG], ys1[DEG], cc[DEG];
+  double cl_[DEG];   // clamped residuals of the point last given to cost(): commit() takes them from here
   double pk[2], pk2[2], G2;   // k = 2 projector (fixed_rank_psd_sym.py:107-113; Pm = 1)
 
   __host__ __device__ static constexpr size_t lds_bytes() {
@@ -113,7 +120,7 @@ struct QuadCtx {
               ((kind == GIK_TERM_EQ || kind == GIK_TERM_UPPER) ? 0x400u : 0u) |
               ((kind == GIK_TERM_EQ || kind == GIK_TERM_LOWER) ? 0x800u : 0u) | ((uint32_t)meta_term(m) << 16);
       sh_tg[s * WAVE + lane] = 0.0;
-      ys0[s] = ys1[s] = cc[s] = 0.0;
+      ys0[s] = ys1[s] = cc[s] = cl_[s] = 0.0;
     }
     pk[0] = pk[1] = pk2[0] = pk2[1] = G2 = 0.0;
     sh_P[lane] = make_double2(0.0, 0.0);
@@ -124,15 +131,24 @@ struct QuadCtx {
   // per problem (divergent: only the lanes of the slot that starts problem b)
   __device__ inline void load_targets(const double *targets_b) {
 #pragma unroll
-    for (int s = 0; s < DEG; ++s) sh_tg[s * WAVE + lane] = targets_b[sl[s] >> 16];
+    for (int s = 0; s < DEG; ++s) sh_tg[s * WAVE + lane] = targets_b[opaque(sl[s]) >> 16];
+  }
+  // The slot word through an empty asm: what is derived from it at this use (the clamp bounds of residual() as
+  // doubles, the 64-bit offsets of load_targets()) is then computed HERE, a few integer instructions once per outer
+  // iteration, instead of being hoisted out of the kernel's loop and kept live across the tCG solve -- round 4's
+  // build held 2 x DEG bounds and DEG offsets that way, most of them in scratch.
+  __device__ static inline uint32_t opaque(uint32_t m) {
+    asm volatile("" : "+v"(m));
+    return m;
   }
   __device__ inline const double2 &row(const double2 *base, int s) const {
     return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + (sl[s] & 0x3ffu));
   }
   // clamp(u, lo, hi) of slot s (the bounds differ from 0 in their upper word only)
   __device__ inline double residual(int s, double u) const {
-    const double lo = __hiloint2double((sl[s] & 0x400u) ? (int)0xfff00000 : 0, 0);
-    const double hi = __hiloint2double((sl[s] & 0x800u) ? 0x7ff00000 : 0, 0);
+    const uint32_t m = opaque(sl[s]);
+    const double lo = __hiloint2double((m & 0x400u) ? (int)0xfff00000 : 0, 0);
+    const double hi = __hiloint2double((m & 0x800u) ? 0x7ff00000 : 0, 0);
     return fmin(fmax(u, lo), hi);
   }
 
@@ -150,6 +166,7 @@ struct QuadCtx {
       const double a = x0 - r.x, b = x1 - r.y;
       const double d = fma(b, b, a * a);
       const double cl = residual(s, sh_tg[s * WAVE + lane] - d);
+      cl_[s] = cl;
       f = fma(cl, cl, f);
     }
     return 0.5 * quad_sum(has_node ? f : 0.0);
@@ -157,6 +174,8 @@ struct QuadCtx {
 
   // egrad at the point whose rows are in sh_P (lgrad / jgrad, costs.py:98-123, 20-35) and the
   // per-slot constants of the Hessian there.  No cross-lane step: may be called by some slots only.
+  // The clamped residuals are those cost() formed for this point (cl_: the same bits as recomputing them, which
+  // until round 5 cost a squared distance, a target read and two clamps per slot a second time).
   __device__ inline void commit(double &g0, double &g1) {
     const double2 o = sh_P[own];
     double G0 = 0.0, G1 = 0.0;
@@ -164,8 +183,7 @@ struct QuadCtx {
     for (int s = 0; s < DEG; ++s) {
       const double2 r = row(sh_P, s);
       const double a = o.x - r.x, b = o.y - r.y;
-      const double d = fma(b, b, a * a);
-      const double cl = residual(s, sh_tg[s * WAVE + lane] - d);
+      const double cl = cl_[s];
       // active: an equality always, a hinge iff its clamped residual is non-zero
       const bool act = ((sl[s] & 0xc00u) == 0xc00u) || (cl != 0.0);
       const double c = -cl;
@@ -232,12 +250,11 @@ struct QuadCtx {
       u3 = -b * s * i2c;
       const bool risky = !(fabs(a + b) >= 0.05 * (a + c));
       if (quad_any(risky)) {
-        double e0, e1, e2, e3;
-        planar_omega_by_elimination(X00, X01, X11, e0, e1, e2, e3);
-        u0 = risky ? e0 : u0;
-        u1 = risky ? e1 : u1;
-        u2 = risky ? e2 : u2;
-        u3 = risky ? e3 : u3;
+        const Omega4 e = planar_omega_by_elimination(X00, X01, X11);
+        u0 = risky ? e.u0 : u0;
+        u1 = risky ? e.u1 : u1;
+        u2 = risky ? e.u2 : u2;
+        u3 = risky ? e.u3 : u3;
       }
     }
     pk[0] = -hm * x1;
