@@ -442,7 +442,7 @@ class Bench:
                   "bytes": int(st.shape[0]) * int(st.shape[1]) * 8,
                   "backend": dist.get_backend() if dist.is_initialized() else None,
                   "sha256": hashlib.sha256(np.ascontiguousarray(st).tobytes()).hexdigest(),
-                  "note": "per-problem results of all ranks on rank 0, the ONE collective of the job (all_gather over "
+                  "note": "per-problem results of all ranks on rank 0, the ONE collective of the job (gather to rank 0 over "
                           "RCCL): q [n] + " + ", ".join(gd.RESULT_STATS) + " -- the table of "
                           "graphik_amd.distributed.solve_batch_sharded (the points Y travel on request: with_Y)"}
         _, _, ginfo = gd.unpack_results(st, robot.n)
@@ -539,6 +539,10 @@ class Bench:
                 "achieved": pf / (prep_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": pf / (prep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "flops_per_launch": pf,
                 "mds_columns_median": float(np.median(K_local)),
+                # SURVEY 8(d) bytes of this kernel: goal pose in, per-term targets + initial point (+ the MDS column
+                # count) out; `traffic` (HBM bytes per launch from the PMC passes, null if unprofiled) is filled below
+                "bytes_per_launch": float(B * (8 * (k + 1) ** 2 + 8 * T + 8 * N * k + 4)),
+                "traffic": None,
                 "note": "goal distances + bound smoothing + MDS initial point, one wavefront (workgroup) per goal; "
                         "SURVEY 8(d): F_init = 2 * 9 N^3 + 9 K^3 per goal with the K the kernel reports, + 4 N^3 for "
                         "Floyd-Warshall (UPPER) and the max-plus pass (LOWER); LDS resident, bound by instruction "
@@ -547,20 +551,30 @@ class Bench:
             out["kernels"] = {"prepare_ms": None, "solve_ms": kernel_ms, "recover_ms": None, "dominant": out["roofline"]["kernel"]}
         # HBM traffic of the solve kernel from the PMC passes of the SAME workload (tools/profile.sh:
         # rocprofv3 cannot run inside this process), newest round first; null for unprofiled workloads
-        tags = {("lwa4d", 4096): ["r04", "r03", "r02"], ("ur10_table", 4096): ["r04_c3"],
-                ("kuka", 65536): ["r04_c4", "r03_c4"], ("kuka", 8192): ["r04_c4share", "r03_c4share"],
-                ("planar10", 65536): ["r04_c5", "r03_c5", "r02_c5"]}
+        tags = {("lwa4d", 4096): ["r05", "r04", "r03", "r02"], ("ur10_table", 4096): ["r05_c3", "r04_c3"],
+                ("kuka", 65536): ["r05_c4", "r04_c4", "r03_c4"], ("kuka", 8192): ["r05_c4share", "r04_c4share", "r03_c4share"],
+                ("planar10", 65536): ["r05_c5", "r04_c5", "r03_c5", "r02_c5"]}
+        out["roofline"]["traffic_measured"] = None
         for tag in ([] if intended else tags.get((robot_name, B), [])):
             traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json" if tag == "r02" else f"{tag}_hbm_traffic.json")
             if not os.path.exists(traffic_file):
                 continue
             try:
                 tj = json.load(open(traffic_file))
+                src = (f"profiles/{os.path.basename(traffic_file)}: rocprofv3 --pmc passes of this workload in a "
+                       "separate run (tools/profile.sh + tools/summarize_prof.py), not measured by the process "
+                       "that printed this line")
                 out["roofline"]["traffic"] = tj.get("bytes_per_launch")
-                out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(traffic_file)}: rocprofv3 --pmc "
-                                                     "passes of this workload in a separate run "
-                                                     "(tools/profile.sh + tools/summarize_prof.py), not "
-                                                     "measured by the process that printed this line")
+                out["roofline"]["traffic_ratio"] = tj.get("bytes_per_launch") / hbm_bytes if hbm_bytes else None
+                out["roofline"]["traffic_source"] = src
+                out["roofline"]["traffic_measured"] = "profiles (separate rocprofv3 run), not in-process"
+                pj = tj.get("prepare")
+                if pj and "roofline_prepare" in out:
+                    rp = out["roofline_prepare"]
+                    rp["traffic"] = pj.get("bytes_per_launch")
+                    rp["traffic_ratio"] = pj.get("bytes_per_launch") / rp["bytes_per_launch"]
+                    rp["lds_bank_conflict_ratio"] = pj.get("lds_bank_conflict_ratio")
+                    rp["traffic_source"] = src
                 break
             except Exception:
                 pass
@@ -598,7 +612,8 @@ def brief(o):
             "goals_total": o["config"]["goals_total"], "batch_per_gpu": o["config"]["batch_per_gpu"],
             "kernel": r["kernel"], "kernel_ms": r["kernel_ms"],
             "roofline": {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
-                         "frac": r["frac"], "frac_executed": r["frac_executed"], "traffic": r["traffic"]},
+                         "frac": r["frac"], "frac_executed": r["frac_executed"], "traffic": r["traffic"],
+                         "traffic_ratio": r.get("traffic_ratio"), "traffic_measured": r.get("traffic_measured")},
             "success_rate": o["success_rate"], "frac_maxiter": o["frac_maxiter"],
             "median_pos_err_m": o["median_pos_err_m"], "median_rot_err_rad": o["median_rot_err_rad"],
             "outer_iterations": o["outer_iterations"],
@@ -654,6 +669,24 @@ def main():
                                     "3 steps after 1 warm-up)"}
     b.gd.shutdown()
     if b.rank == 0:
+        # LAST key of the line: one compact record per BASELINE config (the driver keeps the tail of a long line)
+        def tiny(o, r=None):
+            r = r or o.get("roofline") or {}
+            rp = o.get("roofline_prepare") or {}
+            kn = o.get("kernels") or {}
+            sig = lambda v: None if v is None else float("%.4g" % v)
+            return {"value": sig(o.get("value")), "ms": sig(o.get("ms_per_step")), "frac": sig(r.get("frac")),
+                    "frac_exec": sig(r.get("frac_executed")), "traffic_x": sig(r.get("traffic_ratio")),
+                    "prep_ms": sig(kn.get("prepare_ms")), "solve_ms": sig(kn.get("solve_ms")),
+                    "prep_frac": sig(rp.get("frac")), "prep_traffic_x": sig(rp.get("traffic_ratio")),
+                    "cpu": sig((o.get("cpu_baseline") or {}).get("value"))}
+        summ = {cfg if cfg else "custom": tiny(out)}
+        for name, o in (out.get("configs") or {}).items():
+            if o and "value" in o:
+                summ[name] = tiny(o)
+        out["summary"] = {"unit": "solves/s; ms per step; roofline fractions of the fp64 vector peak (algorithmic / executed); "
+                                  "traffic_x = HBM bytes per launch (PMC, profiles/) / algorithmic bytes; cpu = oracle solves/s",
+                          "traffic_measured": "profiles/ (separate rocprofv3 --pmc runs), not in-process", **summ}
         print(json.dumps(out), flush=True)
 
 

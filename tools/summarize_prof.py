@@ -51,8 +51,15 @@ json.dump(summary, open(os.path.join(out, f"{tag}_pmc_per_launch.json"), "w"), i
 solve = next(k for k in summary if "rtr_wave_kernel" in k or "rtr_block_kernel" in k or "rtr_npt_kernel" in k or "rtr_quad_kernel" in k)
 fetch = summary[solve]["FETCH_SIZE"] * 1024 * 2
 write = summary[solve]["WRITE_SIZE"] * 1024
+prep = next((k for k in summary if "prep_quad_kernel" in k or "prep_wave_kernel" in k or "prep_block_kernel" in k), None)
+prep_entry = None
+if prep and "FETCH_SIZE" in summary[prep]:
+    pf, pw = summary[prep]["FETCH_SIZE"] * 1024 * 2, summary[prep]["WRITE_SIZE"] * 1024
+    prep_entry = {"kernel": prep, "bytes_per_launch": pf + pw, "fetch_bytes_corrected": pf, "write_bytes": pw,
+                  "lds_bank_conflict_ratio": (summary[prep]["SQ_LDS_BANK_CONFLICT"] / summary[prep]["SQ_LDS_IDX_ACTIVE"]
+                                              if summary[prep].get("SQ_LDS_IDX_ACTIVE") else None)}
 json.dump({"kernel": solve, "bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch,
-           "write_bytes": write,
+           "write_bytes": write, "prepare": prep_entry,
            "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, "
                   "tools/profile.sh %s), bench.py --steps 2 --warmup 1, mean over the dispatches; " % tag +
                   "FETCH_SIZE (KiB) x1024 x2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM "
