@@ -92,6 +92,10 @@ def parse_args(argv=None):
     ap.add_argument("--serving-streams", type=int, default=16,
                     help="extra, separately labelled measurement after the timed region: the same "
                          "batches issued round-robin on this many HIP streams (0 = skip)")
+    ap.add_argument("--hessian-form", choices=["column", "per_edge"], default="column",
+                    help="3-D arms on the wavefront kernel: how lhess is rendered (gik_template_desc.hessian_form); "
+                         "per_edge = s = y.w once per edge as costs.py:186-203 writes it (tighter parity, slower product); "
+                         "the BASELINE line is the default, column")
     ap.add_argument("--intended", action="store_true",
                     help="ur10_table only: the opt-in fixed-anchor formulation with the robot<->obstacle "
                          "hinges the reference means to create (SURVEY 8(f)3); NOT the reference's observable "
@@ -316,7 +320,8 @@ class Bench:
             N, k = len(anch.free), 3
             T = anch.template.T + len(anch.pin)              # terms the Hessian product sees
         else:
-            prob = BatchProblem(graph, use_limits=use_limits, device=dev)
+            prob = BatchProblem(graph, use_limits=use_limits, device=dev,
+                                params=({"hessian_form": 1} if self.args.hessian_form == "per_edge" else None))
             N, k, T = graph.number_of_nodes(), graph.dim, prob.template.T
         tpl = prob.template
         on_device = prob.device_pipeline
@@ -464,6 +469,8 @@ class Bench:
             kernel_name = f"rtr_quad_kernel<{info['max_terms_per_node']}> (four planar problems per wavefront)"
         else:
             kernel_name = f"rtr_wave_kernel<{k},{info['max_terms_per_node'] if info else prob.template.maxdeg}>"
+            if info and info.get("hessian_form"):
+                kernel_name += " (per-edge product form)"
         flops_exec = executed_flops(N, k, T, info if anch is None else None, lowrank_local,
                                     exec_local, outer_local, acc_local)
         executed_tf = flops_exec / (kernel_ms * 1e-3) / 1e12

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GIK_LIB_PATH") or os.path.join(_HERE, "lib", "libgraphik_amd.so")
 
 TERM_EQ, TERM_LOWER, TERM_UPPER = 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class TemplateDesc(C.Structure):
@@ -29,11 +29,12 @@ class TemplateDesc(C.Structure):
         ("planar_proj_exact", C.c_int32), ("force_block_path", C.c_int32),
         ("waves_per_cu", C.c_int32), ("slice_outer_its", C.c_int32), ("debug_flags", C.c_int32),
         ("solver", C.c_int32), ("cg_minstepsize", C.c_double), ("cg_orth_value", C.c_double),
-        ("cg_beta_type", C.c_int32), ("clique_closed_form", C.c_int32),
+        ("cg_beta_type", C.c_int32), ("clique_closed_form", C.c_int32), ("hessian_form", C.c_int32),
     ]
 
 
 CLIQUE_AUTO, CLIQUE_OFF, CLIQUE_DENSE = 0, 1, 2
+HESS_COLUMN, HESS_PER_EDGE = 0, 1
 
 
 class TemplateInfo(C.Structure):
@@ -42,7 +43,7 @@ class TemplateInfo(C.Structure):
                 ("n_cu", C.c_int32), ("lds_bytes", C.c_int32), ("clique_closed_form", C.c_int32),
                 ("anchored", C.c_int32), ("has_pipeline", C.c_int32), ("prepare_is_block", C.c_int32),
                 ("node_per_lane", C.c_int32), ("problems_per_wave", C.c_int32), ("goals_per_wave", C.c_int32),
-                ("reserved", C.c_int32 * 1)]
+                ("hessian_form", C.c_int32)]
 
 
 SOLVER_TRUST_REGIONS, SOLVER_CONJUGATE_GRADIENT = 0, 1

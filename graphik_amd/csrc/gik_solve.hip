@@ -27,6 +27,7 @@
 #include "gik_rtr.hip.h"
 #include "gik_rtrv.hip.h"
 #include "gik_wave.hip.h"
+#include "gik_wave_strict.hip.h"
 #include "graphik_amd.h"
 
 namespace gik {
@@ -215,11 +216,14 @@ __device__ inline void stage_lds(double *tiles, uint32_t *meta, const uint32_t *
 // XCDs idle behind a few stragglers; the queue keeps every SIMD busy until the end.
 // (the fixed-anchor variant holds 34 KB of LDS per wave: four waves per CU, one per SIMD, so it may
 // as well have that SIMD's whole register file -- at two waves per SIMD it spilled into the hot loop)
-template <int K, int MAXDEG, bool THETA_ONE, bool ANCH = false, bool MIG = false>
+// STRICT: the Hessian product term by term as costs.py:186-203 forms it (gik_wave_strict.hip.h;
+// gik_template_desc.hessian_form = GIK_HESS_PER_EDGE), k = 3 free-free graphs
+template <int K, int MAXDEG, bool THETA_ONE, bool ANCH = false, bool MIG = false, bool STRICT = false>
 __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs a) {
   static_assert(!ANCH || K == 3, "the fixed-anchor formulation is 3-D");
   static_assert(!MIG || !ANCH, "tail spreading: two waves per SIMD, i.e. not the anchored variant");
-  using Ctx = WaveCtx<K, MAXDEG, ANCH>;
+  static_assert(!STRICT || (K == 3 && !ANCH), "the per-edge product form: 3-D free-free graphs");
+  using Ctx = std::conditional_t<STRICT, WaveCtxStrict<MAXDEG>, WaveCtx<K, MAXDEG, ANCH>>;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int NK = a.N * K;
@@ -487,9 +491,9 @@ struct KatArgs {
   NptTabs nt;
 };
 
-template <int K, int MAXDEG, bool ANCH = false>
+template <int K, int MAXDEG, bool ANCH = false, bool STRICT = false>
 __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
-  using Ctx = WaveCtx<K, MAXDEG, ANCH>;
+  using Ctx = std::conditional_t<STRICT, WaveCtxStrict<MAXDEG>, WaveCtx<K, MAXDEG, ANCH>>;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
@@ -1352,17 +1356,25 @@ struct Variant {
   kat_fn kat_anch;
   lds_fn lds_anch;
   solve_fn solve_mig;    // theta == 1 with tail spreading (MigCtl), or null
+  solve_fn solve_strict, solve_strict_mig;   // hessian_form = GIK_HESS_PER_EDGE (k = 3, theta == 1), or null
+  kat_fn kat_strict;
 };
 #define GIK_VARIANT(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
-   lds_bytes_of<K, D>, nullptr, nullptr, nullptr, nullptr}
+   lds_bytes_of<K, D>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
+#define GIK_VARIANT_S(K, D) \
+  {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
+   lds_bytes_of<K, D>, nullptr, nullptr, nullptr, nullptr, rtr_wave_kernel<K, D, true, false, false, true>, \
+   rtr_wave_kernel<K, D, true, false, true, true>, kat_wave_kernel<K, D, false, true>}
 #define GIK_VARIANT_A(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
-   lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, nullptr}
+   lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, nullptr, \
+   nullptr, nullptr, nullptr}
 #define GIK_VARIANT_AM(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
    lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, \
-   rtr_wave_kernel<K, D, true, false, true>}
+   rtr_wave_kernel<K, D, true, false, true>, rtr_wave_kernel<K, D, true, false, false, true>, \
+   rtr_wave_kernel<K, D, true, false, true, true>, kat_wave_kernel<K, D, false, true>}
 // anchored templates only: the free-free formulation with more than 10 terms at a node runs on the
 // workgroup kernels (the 20-slot wavefront variant needed 796 B of scratch per lane: measured on the
 // two-end-effector tree of tests/golden/tree5.npz, 13 terms, 144 k against 382 k solves/s;
@@ -1370,8 +1382,8 @@ struct Variant {
 // workgroup kernels on the planar trees -- both stay)
 #define GIK_VARIANT_ANCH_ONLY(K, D) \
   {K, D, nullptr, nullptr, nullptr, nullptr, lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, \
-   kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, nullptr}
-static const Variant kVariants[] = {GIK_VARIANT_AM(3, 9), GIK_VARIANT(3, 10), GIK_VARIANT_ANCH_ONLY(3, 20),
+   kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, nullptr, nullptr, nullptr, nullptr}
+static const Variant kVariants[] = {GIK_VARIANT_AM(3, 9), GIK_VARIANT_S(3, 10), GIK_VARIANT_ANCH_ONLY(3, 20),
                                     GIK_VARIANT(2, 6), GIK_VARIANT(2, 16), GIK_VARIANT(2, 31)};
 
 }  // namespace gik
@@ -1408,6 +1420,7 @@ struct gik_template {
                             // (a slot marked in_use belongs to its call: blocking work happens outside the lock)
   std::mutex ev_mutex;      // ev_solve0 / ev_solve1 (anchored templates)
   int clique_mode = 0;      // gik_template_desc::clique_closed_form as resolved at creation
+  bool hess_per_edge = false;   // gik_template_desc::hessian_form = GIK_HESS_PER_EDGE on the wavefront kernel (k = 3)
   // time-slicing workspaces (re-queue ring + paused state), a small pool handed out round-robin;
   // a launch that gets a slot still in use by an earlier launch waits for it on its stream
   struct SliceWs {
@@ -1536,6 +1549,7 @@ void gik_default_params(gik_template_desc *d) {
   d->cg_orth_value = 10e10;     // :57
   d->cg_beta_type = 3;          // :58  BetaTypes[3] = HagerZhang
   d->clique_closed_form = GIK_CLIQUE_AUTO;
+  d->hessian_form = GIK_HESS_COLUMN;
 }
 
 void gik_default_cg_params(gik_template_desc *d) {
@@ -1576,6 +1590,8 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   if (d->cg_beta_type < 0 || d->cg_beta_type > 3) return fail("cg_beta_type must be 0..3");
   if (d->clique_closed_form < GIK_CLIQUE_AUTO || d->clique_closed_form > GIK_CLIQUE_DENSE)
     return fail("clique_closed_form must be GIK_CLIQUE_AUTO, _OFF or _DENSE");
+  if (d->hessian_form != GIK_HESS_COLUMN && d->hessian_form != GIK_HESS_PER_EDGE)
+    return fail("hessian_form must be GIK_HESS_COLUMN or GIK_HESS_PER_EDGE");
 
   bool is_block = d->N * d->k > WAVE || d->N > 32 || d->force_block_path != 0;
   if (d->N < 2 || d->N > BLOCK_MAXN) return fail("N must be in [2, 128]");
@@ -1949,6 +1965,15 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   t->T = T;
   t->maxdeg = is_block ? SL : MD;
   t->variant = var;
+  // the per-edge product form concerns the one-unknown-per-lane kernel only (every other kernel forms s = y . w per
+  // edge anyway); there it exists for k = 3, TrustRegions, theta = 1, free-free graphs
+  if (d->hessian_form == GIK_HESS_PER_EDGE && !is_block && d->k == 3) {
+    if (ad || d->solver != GIK_SOLVER_TRUST_REGIONS || d->theta != 1.0 || !var->solve_strict) {
+      delete t;
+      return fail("hessian_form = GIK_HESS_PER_EDGE: wavefront kernel of 3-D free-free graphs, TrustRegions, theta = 1 only");
+    }
+    t->hess_per_edge = true;
+  }
   t->p.mingradnorm = d->mingradnorm;
   t->p.theta = d->theta;
   t->p.kappa = d->kappa;
@@ -2529,7 +2554,8 @@ static int launch_kat(const gik_template *t, int mode, const double *d_Y, const 
       hipLaunchKernelGGL(kat_block_kernel<2>, dim3(B), dim3(BLOCK_NT), t->smem_bytes,
                          (hipStream_t)stream, a, t->SL);
   } else {
-    hipLaunchKernelGGL(t->variant->kat, dim3(B), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(t->hess_per_edge ? t->variant->kat_strict : t->variant->kat, dim3(B), dim3(WAVE), t->smem_bytes,
+                       (hipStream_t)stream, a);
   }
   HIP_OK(hipGetLastError());
   return 0;
@@ -2703,7 +2729,8 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   // (At one wave per SIMD -- batches up to 6 problems per SIMD -- round-robin slicing LOSES 5-8 %: a
   // straggler that happens to start at t = 0 is better off keeping its slot than sharing it for the
   // first ~20 ms; measured on 4096 LWA4D / KUKA / UR10 goals, four seeds each, tools/attic/dev_rr_midbatch.py.)
-  const bool mig = !t->is_block && !cg && !t->anchored && t->variant->solve_mig && t->p.theta == 1.0 &&
+  const bool mig = !t->is_block && !cg && !t->anchored && t->variant->solve_mig &&
+                   (!t->hess_per_edge || t->variant->solve_strict_mig) && t->p.theta == 1.0 &&
                    wpc > 4 && B > grid && !(a.dbg & (1 | 512));
   gik_template::SliceWs *sw = nullptr;
   if (slice > 0 || mig) {
@@ -2785,6 +2812,7 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   } else {
     hipLaunchKernelGGL(t->anchored ? t->variant->solve_anch
                        : cg        ? t->variant->solve_cg
+                       : t->hess_per_edge ? (mig ? t->variant->solve_strict_mig : t->variant->solve_strict)
                        : mig       ? t->variant->solve_mig
                                    : (t->p.theta == 1.0 ? t->variant->solve : t->variant->solve_theta),
                        dim3(grid), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);
@@ -2815,6 +2843,7 @@ int gik_template_get_info(const gik_template *t, gik_template_info *info) {
   info->n_cu = t->n_cu;
   info->lds_bytes = (int32_t)t->smem_bytes;
   info->clique_closed_form = t->clique_mode;
+  info->hessian_form = t->hess_per_edge ? GIK_HESS_PER_EDGE : GIK_HESS_COLUMN;
   info->anchored = t->anchored ? 1 : 0;
   info->has_pipeline = t->has_pipe ? 1 : 0;
   info->prepare_is_block = t->prep_block ? 1 : 0;

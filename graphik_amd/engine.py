@@ -111,13 +111,15 @@ class Template:
                 raise KeyError(f"unknown solver parameter {key!r}")
             if key == "clique_closed_form" and isinstance(val, str):
                 val = {"auto": _ffi.CLIQUE_AUTO, "off": _ffi.CLIQUE_OFF, "dense": _ffi.CLIQUE_DENSE}[val]
-            setattr(d, key, int(val) if key in ("maxiter", "cg_beta_type", "clique_closed_form") else val)
+            if key == "hessian_form" and isinstance(val, str):
+                val = {"column": _ffi.HESS_COLUMN, "per_edge": _ffi.HESS_PER_EDGE}[val]
+            setattr(d, key, int(val) if key in ("maxiter", "cg_beta_type", "clique_closed_form", "hessian_form") else val)
         self.params = {f: getattr(d, f) for f in ("mingradnorm", "maxiter", "maxinner", "mininner",
                                                    "theta", "kappa", "rho_prime",
                                                    "rho_regularization", "planar_proj_exact",
                                                    "force_block_path", "waves_per_cu",
                                                    "slice_outer_its", "debug_flags", "cg_minstepsize",
-                                                   "cg_orth_value", "cg_beta_type", "clique_closed_form")}
+                                                   "cg_orth_value", "cg_beta_type", "clique_closed_form", "hessian_form")}
         self.params["solver"] = self.solver
         h = C.c_void_p()
         self.anchored = anchored is not None

@@ -101,7 +101,7 @@ class RiemannianSolver:
             raise ValueError("params[\"solver\"] must be one of 'ConjugateGradient', 'TrustRegions'")
         for k in ("maxinner", "mininner", "rho_prime", "rho_regularization", "planar_proj_exact",
                   "force_block_path", "waves_per_cu", "slice_outer_its", "debug_flags",
-                  "clique_closed_form"):
+                  "clique_closed_form", "hessian_form"):
             if k in params:
                 self.tr_params[k] = params[k]
         self.device = params.get("device", None)

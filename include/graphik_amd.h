@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GIK_ABI_VERSION 4
+#define GIK_ABI_VERSION 5
 
 /* Residual-term kinds: one "term" per (index pair, kind) exactly as the loops of
  * costs.py:80-207 visit them: equality (omega != 0), lower hinge (psi_L != 0), upper hinge
@@ -106,7 +106,17 @@ typedef struct {
    * accept / reject threshold can differ from a run with GIK_CLIQUE_OFF (which sums the terms in
    * the reference's order).  gik_stats.flags bit 0 and gik_template_get_info report what ran.   */
   int32_t clique_closed_form; /* GIK_CLIQUE_AUTO (default) | GIK_CLIQUE_OFF | GIK_CLIQUE_DENSE     */
+  /* One-unknown-per-lane wavefront kernel, k = 3 (graphs of N * k <= 64 unknowns: the arms), TrustRegions, theta = 1:
+   * how lhess (costs.py:175-207) is rendered.  GIK_HESS_COLUMN (default): rows of the 3 x 3 blocks 2 a y y^T + c I,
+   * cached per accepted point, times the neighbour's entries -- the cheapest form for that layout, but the scalar
+   * s = y . (W_i - W_j) of costs.py:186-203 is never formed, and truncated CG then needs ~7 % more Hessian products
+   * than the reference's arithmetic from the same start points (7-DOF arms end 8e-3 rad from the reference in the
+   * median instead of 2.5e-3; both inside the band the reference's own two code paths span).  GIK_HESS_PER_EDGE:
+   * s once per edge, t = 2 s a y + c w as written -- the form every other kernel of the library uses -- at ~25 % more
+   * time per product (measured price: DESIGN.md 4.1).  Graphs that run on other kernels accept either value.  */
+  int32_t hessian_form;
 } gik_template_desc;
+enum { GIK_HESS_COLUMN = 0, GIK_HESS_PER_EDGE = 1 };
 
 enum { GIK_SOLVER_TRUST_REGIONS = 0, GIK_SOLVER_CONJUGATE_GRADIENT = 1 };
 enum {
@@ -204,7 +214,7 @@ typedef struct {
                                   least 12 problems per CU; else 1 (0: block) */
   int32_t goals_per_wave;      /* prepare kernel: 4 = graph of at most 16 nodes, four goals to a wavefront
                                   (prep_quad_kernel); 1 = one (prep_wave_kernel); 0 = workgroup per goal / no pipeline */
-  int32_t reserved[1];
+  int32_t hessian_form;        /* GIK_HESS_* in effect on the wavefront kernel (GIK_HESS_COLUMN elsewhere)          */
 } gik_template_info;
 int gik_template_get_info(const gik_template *t, gik_template_info *info);
 

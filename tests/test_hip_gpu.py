@@ -34,7 +34,10 @@ def test_cost_grad_hess_proj_known_answers(torch_cuda, name):
     half empty.)"""
     from oracle import c_oracle as co
     d = load_golden(name)
-    templates = [_template(d)] + ([_template(d, debug_flags=16384)] if int(d["dim"]) == 2 else [])
+    templates = [_template(d)] + ([_template(d, debug_flags=16384)] if int(d["dim"]) == 2 else
+                                  [_template(d, hessian_form=1)])      # (3-D: + the per-edge product form, WaveCtxStrict)
+    if int(d["dim"]) == 3:
+        assert templates[1].info["hessian_form"] == 1 and templates[0].info["hessian_form"] == 0
     for T in templates:
         key = "lim" if int(d["use_limits"]) else "nolim"
         tg = T.targets_from_D(d["D_goal"][0])
@@ -146,16 +149,21 @@ def test_trajectory_planar_identical_to_oracle(torch_cuda, name, per_wave):
     assert exact_tail >= len(d["seed"]) // 2
 
 
+# the 3-D solve kernels: wavefront (column-form product, the default), wavefront with the per-edge product form
+# (gik_template_desc.hessian_form = GIK_HESS_PER_EDGE, round 5), workgroup, node-per-lane
+_PATH_PARAMS = {"wave": {"force_block_path": 0}, "wave_per_edge": {"force_block_path": 0, "hessian_form": 1},
+                "block": {"force_block_path": 1}, "npt": {"force_block_path": 2}}
+
+
 def _hip_traces(d, path):
     from graphik_amd.engine import Template
-    T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=3, use_limits=True,
-                               params={"force_block_path": {"wave": 0, "block": 1, "npt": 2}[path]})
+    T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=3, use_limits=True, params=_PATH_PARAMS[path])
     r = T.solve(d["Y_init"], T.targets_from_D(d["D_goal"]), trace_cap=48)
     tr = {k: v.cpu().numpy() for k, v in r["trace"].items()}
     return r, [{k: tr[k][g] for k in tr} for g in range(len(d["seed"]))]
 
 
-@pytest.mark.parametrize("path", ["wave", "block"])
+@pytest.mark.parametrize("path", ["wave", "wave_per_edge", "block", "npt"])
 @pytest.mark.parametrize("name", SCENARIOS_3D)
 def test_trajectory_prefix_3d(torch_cuda, name, path):
     """identical discrete decisions and f, |grad| to 1e-8 for the outer iterations
@@ -208,7 +216,7 @@ def test_trajectory_prefix_3d(torch_cuda, name, path):
     assert k_hip.sum() >= 0.85 * k_ref.sum(), (k_hip, k_ref)
 
 
-@pytest.mark.parametrize("path", ["wave", "block", "npt"])
+@pytest.mark.parametrize("path", ["wave", "wave_per_edge", "block", "npt"])
 @pytest.mark.parametrize("name", SCENARIOS_3D)
 def test_finals_statistical_3d(torch_cuda, name, path):
     """End-to-end parity of the recovered joint configurations (same IK branch,
@@ -314,7 +322,7 @@ def test_gradient_roundoff_is_horizontal(torch_cuda, name):
         assert np.abs(G[b].sum(axis=0)).max() < 1e-12 * nrm   # translation-free as well
 
 
-@pytest.mark.parametrize("path", ["wave", "block", "npt"])
+@pytest.mark.parametrize("path", ["wave", "wave_per_edge", "block", "npt"])
 def test_effort_parity_ur10(torch_cuda, path):
     """Same work as the reference's algorithm, not only the same answers: on random UR10 goals no
     tCG solve runs into maxinner (the reference's never do; a search direction that keeps the
@@ -329,8 +337,9 @@ def test_effort_parity_ur10(torch_cuda, path):
     from oracle import c_oracle as co
     from graphik_amd.solvers.riemannian_solver import BatchProblem
     robot, graph = make_graph("ur10")
-    prob = BatchProblem(graph, use_limits=True, params={"force_block_path": {"wave": 0, "block": 1, "npt": 2}[path]})
-    assert prob.template.info["is_block"] == int(path != "wave")
+    prob = BatchProblem(graph, use_limits=True, params=_PATH_PARAMS[path])
+    assert prob.template.info["is_block"] == int(not path.startswith("wave"))
+    assert prob.template.info["hessian_form"] == int(path == "wave_per_edge")
     B = 192
     rng = np.random.RandomState(3)
     Tg = robot.fk_batch(-np.pi + 2 * np.pi * rng.rand(B, robot.n))

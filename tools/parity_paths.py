@@ -18,7 +18,7 @@ from graphik_amd.graphs.graph_revolute import joint_variables_revolute_batch
 from graphik_amd.solvers.riemannian_solver import BatchProblem
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-PATHS = {"wave": {}, "block": {"force_block_path": 1}, "npt": {"force_block_path": 2}}
+PATHS = {"wave": {}, "wave_per_edge": {"hessian_form": 1}, "block": {"force_block_path": 1}, "npt": {"force_block_path": 2}}
 out = {}
 for name in ("kuka", "lwa4d", "ur10"):
     d = load_golden(name)
@@ -45,6 +45,11 @@ for name in ("kuka", "lwa4d", "ur10"):
         rec["finals"][path] = [float(np.percentile(dq[conv], q_)) for q_ in (50, 75)]
         Tp = Template.from_matrices(prob.omega, prob.psi_L, prob.psi_U, k=3, use_limits=True, params=params)
         rr = Tp.solve(Y0, targets)
+        ms = []
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); Tp.solve(Y0, targets); e1.record(); torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
         hv, its = rr["inner_total"].cpu().numpy().astype(np.int64), rr["iterations"].cpu().numpy()
         ex = rr["inner_executed"].cpu().numpy().astype(np.int64)
         same = (its < 3000) == (oo["iterations"] < 3000)
@@ -52,7 +57,7 @@ for name in ("kuka", "lwa4d", "ur10"):
                                "hv_executed_ratio": float(ex.sum() / oo["inner_total"].sum()),
                                "median_its": [float(np.median(its)), float(np.median(oo["iterations"]))],
                                "p90_its": [float(np.percentile(its, 90)), float(np.percentile(oo["iterations"], 90))],
-                               "same_convergence_class": float(same.mean())}
+                               "same_convergence_class": float(same.mean()), "solve_ms": float(min(ms))}
     out[name] = rec
     print(name, json.dumps(rec), flush=True)
 os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
