@@ -99,9 +99,16 @@ __device__ inline double wave_sum24_distributed(double (&v)[24]) {
 //   <TL, 1, 2>: one node per lane, two wavefronts (128 threads) per problem: half the per-lane state and
 //               per-node work, every reduction finished through LDS behind a workgroup barrier (two
 //               per Hessian product: the moments, and the solver's eight inner products).
-template <int TL, int NS, int NW>
+//   <TL, 1, 4, true>: one node per lane, FOUR wavefronts per problem -- graphs of 129 .. 255 nodes (round 5: a scene
+//               with more than 112 obstacles used to be refused).  CTG_GLOBAL: the clique's target triangle --
+//               n (n - 1) / 2 doubles, 169 KB at 206 anchors -- lives in a per-workgroup slice of global memory
+//               instead of LDS; it is read by the once-per-outer-iteration walks of cost() / clique_dw() only,
+//               never by a Hessian product.
+template <int TL, int NS, int NW, bool CTG_GLOBAL = false>
 struct NptCtx {
-  static_assert(NS * NW == 2, "128 rows");
+  static_assert((NS == 2 && NW == 1) || NS == 1, "two nodes per lane: the one-wavefront layout only");
+  static_assert(NS * NW == 2 || (NS == 1 && NW == 4), "128 rows, or 256 on four wavefronts");
+  static constexpr int ROWS = WAVE * NS * NW;   // thread slots = rows of the tables below
   static constexpr int NE = 3 * NS;  // entries per lane
   static constexpr int NT = WAVE * NW;   // threads per problem
   static constexpr int NC = 3;
@@ -135,7 +142,7 @@ struct NptCtx {
   double *sh_P;              // [n_rows][4] proposal (cost) / committed point
   double *sh_W;              // [n_wrows + 1][4] direction rows of the nodes that carry slot terms (+ a zero row)
   double *sh_T;              // [2 n_terms + 1][4] per-term vectors: row 2 q = +t_q, row 2 q + 1 = -t_q (+ a zero row)
-  double *sh_ctg;            // [n_pairs] clique target distances, each pair once
+  double *sh_ctg;            // [n_pairs] clique target distances, each pair once (CTG_GLOBAL: global memory)
   double *sh_red;            // NW > 1: [2][NW][32] cross-wave reduction scratch, double buffered
   int red_buf;
   static constexpr int NG = 8;   // packed gather words per lane: 16 entries (two 16-bit rows each)
@@ -156,9 +163,11 @@ struct NptCtx {
 
   __host__ __device__ static constexpr size_t lds_bytes(int n_pairs, int n_wrows, int n_rows, int n_terms) {
     return sizeof(double) * ((size_t)n_rows * NPT_RS + (size_t)(n_wrows + 1) * NPT_RS +
-                             (size_t)(2 * n_terms + 1) * NPT_RS + (size_t)((n_pairs + 1) & ~1) +
+                             (size_t)(2 * n_terms + 1) * NPT_RS + (CTG_GLOBAL ? 0 : (size_t)((n_pairs + 1) & ~1)) +
                              (NW > 1 ? 2 * NW * 32 : 0));
   }
+  // doubles of global workspace per resident workgroup (CTG_GLOBAL)
+  __host__ __device__ static constexpr size_t ctg_doubles(int n_pairs) { return CTG_GLOBAL ? (size_t)((n_pairs + 7) & ~7) : 0; }
 
   __device__ inline bool lead() const { return tid == 0; }
   __device__ inline void ck_put(int i, const double (&v)[NE]) {
@@ -229,13 +238,16 @@ struct NptCtx {
                     (((lane >> 1) & 1) << 4);
       __syncthreads();
       tot = buf[q] + buf[32 + q];
+#pragma unroll
+      for (int w2 = 2; w2 < NW; ++w2) tot += buf[w2 * 32 + q];
       red_buf ^= 1;
     }
     return tot;
   }
 
-  // once per kernel: LDS carve-up, launch-invariant tables
-  __device__ inline void init(const NptTabs &nt, double *smem) {
+  // once per kernel: LDS carve-up, launch-invariant tables (ctg_ws: this workgroup's slice of the global
+  // workspace, CTG_GLOBAL only)
+  __device__ inline void init(const NptTabs &nt, double *smem, double *ctg_ws = nullptr) {
     tid = threadIdx.x;
     lane = tid & 63;
     wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -251,8 +263,13 @@ struct NptCtx {
     sh_P = smem;
     sh_W = sh_P + nt.n_rows * NPT_RS;
     sh_T = sh_W + (n_wrows + 1) * NPT_RS;
-    sh_ctg = sh_T + (2 * n_terms + 1) * NPT_RS;
-    sh_red = sh_ctg + ((n_pairs + 1) & ~1);
+    if constexpr (CTG_GLOBAL) {
+      sh_ctg = ctg_ws;
+      sh_red = sh_T + (2 * n_terms + 1) * NPT_RS;
+    } else {
+      sh_ctg = sh_T + (2 * n_terms + 1) * NPT_RS;
+      sh_red = sh_ctg + ((n_pairs + 1) & ~1);
+    }
     red_buf = 0;
     for (int t = tid; t < nt.n_rows * NPT_RS; t += NT) sh_P[t] = 0.0;
     for (int t = tid; t < (n_wrows + 1) * NPT_RS; t += NT) sh_W[t] = 0.0;
@@ -269,7 +286,7 @@ struct NptCtx {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int r = NS * tid + s;
-      gnode[s] = r < NPT_MAXN ? nt.node_of_row[r] : -1;
+      gnode[s] = r < ROWS ? nt.node_of_row[r] : -1;
       live[s] = gnode[s] >= 0;
       lm[s] = live[s] ? 1.0 : 0.0;
       const int pr = live[s] ? (int)nt.prow_of_slot[r] : 0;

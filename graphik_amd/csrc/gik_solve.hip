@@ -146,6 +146,7 @@ struct SolveArgs {
   SliceState *q_state;             // [B]
   BlockTabs bt;                    // workgroup-per-problem path
   NptTabs nt;                      // node-per-lane path (rtr_npt_kernel)
+  double *npt_ctg_ws = nullptr;    // graphs beyond 128 nodes: [grid][ctg_doubles] clique target triangles (global memory)
 };
 
 // This wave's physical SIMD: XCC_ID[3:0] and the SIMD / CU / SH / SE fields of HW_ID (bits 4-5 and
@@ -489,6 +490,7 @@ struct KatArgs {
   AnchArgs an;
   BlockTabs bt;
   NptTabs nt;
+  double *npt_ctg_ws = nullptr;   // see SolveArgs
 };
 
 template <int K, int MAXDEG, bool ANCH = false, bool STRICT = false>
@@ -709,15 +711,15 @@ __global__ void __launch_bounds__(BLOCK_NT) kat_block_kernel(KatArgs a, int SL) 
 // wavefront per problem.  Persistent; problems are claimed from the same ticket counter / re-queue
 // ring as the workgroup kernel's (FIFO time slicing: the long problems, unknown in advance, must
 // not be the last to START).  LDS-bound at three problems per CU on the table scene.
-template <int TL, int NS, int NW>
+template <int TL, int NS, int NW, bool CTG = false>
 __global__ void __launch_bounds__(WAVE * NW, 1) rtr_npt_kernel(SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ int sh_claim[2];
-  using Ctx = NptCtx<TL, NS, NW>;
+  using Ctx = NptCtx<TL, NS, NW, CTG>;
   const int tid = threadIdx.x;
   const int NK = a.N * 3;
   Ctx cx;
-  cx.init(a.nt, smem);
+  cx.init(a.nt, smem, CTG ? a.npt_ctg_ws + (size_t)blockIdx.x * Ctx::ctg_doubles(a.nt.n_pairs) : nullptr);
   int pass = 0;
   for (;;) {
     int b = 0, resumed = 0;
@@ -798,15 +800,15 @@ __global__ void __launch_bounds__(WAVE * NW, 1) rtr_npt_kernel(SolveArgs a) {
   }
 }
 
-template <int TL, int NS, int NW>
+template <int TL, int NS, int NW, bool CTG = false>
 __global__ void __launch_bounds__(WAVE * NW, 1) kat_npt_kernel(KatArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  using Ctx = NptCtx<TL, NS, NW>;
+  using Ctx = NptCtx<TL, NS, NW, CTG>;
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const int NK = a.N * 3;
   Ctx cx;
-  cx.init(a.nt, smem);
+  cx.init(a.nt, smem, CTG ? a.npt_ctg_ws + (size_t)blockIdx.x * Ctx::ctg_doubles(a.nt.n_pairs) : nullptr);
   cx.load_problem(a.targets ? a.targets + (size_t)b * a.T : nullptr, a.nt);
   double y[Ctx::NE], w[Ctx::NE], res[Ctx::NE];
 #pragma unroll
@@ -849,14 +851,22 @@ struct NptVariant {
   void (*solve)(SolveArgs);
   void (*kat)(KatArgs);
   size_t (*lds)(int, int, int, int);
+  size_t (*ctg)(int);      // doubles of global clique-target workspace per workgroup (0: the triangle sits in LDS)
 };
-template <int TL, int NS, int NW>
+template <int TL, int NS, int NW, bool CTG>
 static size_t npt_lds_of(int n_pairs, int n_wrows, int n_rows, int n_terms) {
-  return NptCtx<TL, NS, NW>::lds_bytes(n_pairs, n_wrows, n_rows, n_terms);
+  return NptCtx<TL, NS, NW, CTG>::lds_bytes(n_pairs, n_wrows, n_rows, n_terms);
 }
-#define GIK_NPT_VARIANT(TL, NS, NW) {TL, NW, rtr_npt_kernel<TL, NS, NW>, kat_npt_kernel<TL, NS, NW>, npt_lds_of<TL, NS, NW>}
-static const NptVariant kNptVariants[] = {GIK_NPT_VARIANT(1, 1, 2), GIK_NPT_VARIANT(4, 1, 2), GIK_NPT_VARIANT(1, 2, 1),
-                                          GIK_NPT_VARIANT(4, 2, 1)};
+template <int TL, int NS, int NW, bool CTG>
+static size_t npt_ctg_of(int n_pairs) {
+  return NptCtx<TL, NS, NW, CTG>::ctg_doubles(n_pairs);
+}
+#define GIK_NPT_VARIANT(TL, NS, NW, CTG) \
+  {TL, NW, rtr_npt_kernel<TL, NS, NW, CTG>, kat_npt_kernel<TL, NS, NW, CTG>, npt_lds_of<TL, NS, NW, CTG>, npt_ctg_of<TL, NS, NW, CTG>}
+// (four wavefronts per problem: graphs of 129 .. 255 nodes, clique targets in global memory)
+static const NptVariant kNptVariants[] = {GIK_NPT_VARIANT(1, 1, 2, false), GIK_NPT_VARIANT(4, 1, 2, false),
+                                          GIK_NPT_VARIANT(1, 2, 1, false), GIK_NPT_VARIANT(4, 2, 1, false),
+                                          GIK_NPT_VARIANT(1, 1, 4, true),  GIK_NPT_VARIANT(4, 1, 4, true)};
 
 // ------------------------------------------------------------------------------------------
 // Four planar problems per wavefront (gik_quad.hip.h): TrustRegions.solve (trust_region.py:112-434)
@@ -1594,7 +1604,13 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     return fail("hessian_form must be GIK_HESS_COLUMN or GIK_HESS_PER_EDGE");
 
   bool is_block = d->N * d->k > WAVE || d->N > 32 || d->force_block_path != 0;
-  if (d->N < 2 || d->N > BLOCK_MAXN) return fail("N must be in [2, 128]");
+  // 255 = what the node-per-lane kernel's 8-bit row fields take (four wavefronts per problem beyond 128 nodes);
+  // every other kernel stops at 128 (checked below, where the kernel is chosen)
+  if (d->N < 2 || d->N > 255) return fail("N must be in [2, 255]");
+  const bool big = d->N > BLOCK_MAXN;
+  if (big && (ad || d->k != 3 || d->solver != GIK_SOLVER_TRUST_REGIONS || d->theta != 1.0 || d->force_block_path == 1))
+    return fail("graphs of more than 128 nodes run on the node-per-lane kernel only: k = 3, TrustRegions, theta = 1, "
+                "not anchored, force_block_path != 1");
   if (d->n_terms < 1 || d->n_terms > 65535) return fail("n_terms out of range");
   const int N = d->N, T = d->n_terms;
   int dbg_eff = d->debug_flags;   // developer override, read once here (never inside a batch call)
@@ -1630,7 +1646,8 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   if (is_block && ad) return fail("anchored templates need N * k <= 64 free unknowns and at most 20 terms per node");
   // workgroup-per-problem tables (BlockTabs)
   int n_clq = 0, Tc = T;
-  std::vector<int> nc_term, clq_term, clq_pair_term, node_of_row(BLOCK_MAXN, -1), wave_sl(2 * BLOCK_WAVES, 0);
+  const int ROWCAP = big ? 256 : BLOCK_MAXN;       // rows of the host-side tables (the workgroup kernels' are 128)
+  std::vector<int> nc_term, clq_term, clq_pair_term, node_of_row(ROWCAP, -1), wave_sl(2 * BLOCK_WAVES, 0);
   std::vector<unsigned short> clq_pid;   // [M][512] compact pair id per (thread, partner), 0xffff = none
   // node-per-lane path: 3-D graphs beyond one wavefront, trust-region solver, theta = 1.
   // force_block_path: 0 = automatic, 1 = the workgroup kernels, 2 = the node-per-lane kernel
@@ -1639,7 +1656,9 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
                           (d->force_block_path == 2 ||
                            (d->force_block_path == 0 && d->N * d->k > WAVE && !getenv("GIK_NO_NPT")));   // (developer A/B switch, read once)
   bool npt_ok = false;
-  const bool npt_two_waves = !(dbg_eff & 2048);      // 2048: one wavefront per problem, two nodes per lane
+  const bool npt_two_waves = big || !(dbg_eff & 2048);      // 2048: one wavefront per problem, two nodes per lane
+  const int npt_NW = big ? 4 : (npt_two_waves ? 2 : 1);     // wavefronts per problem ("two_waves": one node per lane)
+  const int NPT_ROWS = big ? 4 * WAVE : NPT_MAXN;
   int npt_TL = 1, npt_DEG0 = 0, npt_DEG1 = 0, npt_n_wrows = 0, npt_cbase = 0, npt_n_rows = 0, npt_n_terms = 0, npt_term_sync = 0;
   std::vector<int> npt_node_of_row, npt_term_tgt, npt_pair_term;
   std::vector<uint32_t> npt_term_rec;
@@ -1680,7 +1699,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     // ones with more than a slot or two, then sit in wavefronts that have no clique work
     int r = 0;
     for (int pass = 0; pass < 2; ++pass) {
-      if (pass == 1 && n_clq) r = BLOCK_MAXN - (N - n_clq);
+      if (pass == 1 && n_clq) r = ROWCAP - (N - n_clq);
       for (int i = 0; i < N; ++i)
         if ((in_clq[i] != 0) == (pass == 0)) {
           row_of[i] = r;
@@ -1688,7 +1707,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
         }
     }
     // slot entries in row numbering, clique pairs left out; `term` = index in the LDS target table
-    ents.assign(BLOCK_MAXN, {});
+    ents.assign(ROWCAP, {});
     for (int t = 0; t < T; ++t) {
       const int i = d->term_i[t], j = d->term_j[t], kind = d->term_kind[t];
       if (n_clq && kind == GIK_TERM_EQ && in_clq[i] && in_clq[j] && eqterm[(size_t)i * N + j] == t) continue;
@@ -1702,6 +1721,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
       std::stable_sort(e.begin(), e.end(), [](const Ent &a, const Ent &b) {
         return a.j != b.j ? a.j < b.j : a.kind < b.kind;
       });
+    if (!big) {      // tables of the 512-thread workgroup kernels (128 rows)
     const int M = (n_clq + 3) / 4;
     clq_term.assign((size_t)std::max(M, 1) * BLOCK_NT, -1);
     for (int tid = 0; tid < BLOCK_NT; ++tid) {
@@ -1778,6 +1798,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
       }
     }
 
+    }
     // ---- node-per-lane tables (NptTabs, gik_npt.hip.h) ----
     // Two layouts.  Two wavefronts per problem, one node per lane (default): the nodes outside the
     // clique take the first rows, then the clique's nodes, those that carry slot terms first -- every
@@ -1787,7 +1808,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     // slot terms go to EVEN rows where possible, so that a lane's second node has few or none (its
     // gather list is as long as the busiest second node's).
     if (npt_wanted) {
-      const int NSn = npt_two_waves ? 1 : 2, NTn = npt_two_waves ? 2 * WAVE : WAVE;
+      const int NSn = npt_two_waves ? 1 : 2, NTn = npt_NW * WAVE;
       std::vector<int> sdeg(N, 0);
       for (int t : nc_term) {
         ++sdeg[d->term_i[t]];
@@ -1802,8 +1823,8 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
       std::stable_sort(cl_busy.begin(), cl_busy.end(), by_deg);
       std::stable_sort(others.begin(), others.end(), by_deg);
       // nrow[v]: row of node v in the point table; npt_node_of_row[t]: node held by thread slot t
-      npt_node_of_row.assign(NPT_MAXN, -1);
-      npt_prow.assign(NPT_MAXN, 0);
+      npt_node_of_row.assign(NPT_ROWS, -1);
+      npt_prow.assign(NPT_ROWS, 0);
       std::vector<int> nrow(N, -1), nslot(N, -1);
       int n_rows = 0;
       npt_n_helped = 0;
@@ -1854,7 +1875,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
           nrow[v] = r;
         }
         const int start = (n_clq + 1) & ~1;
-        const bool even_only = others.empty() || start + 2 * ((int)others.size() - 1) < NPT_MAXN;
+        const bool even_only = others.empty() || start + 2 * ((int)others.size() - 1) < NPT_ROWS;
         n_rows = n_clq;
         for (size_t q = 0; q < others.size(); ++q) {
           const int r = even_only ? start + 2 * (int)q : n_clq + (int)q;
@@ -1869,11 +1890,11 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
       for (int v = 0; v < N; ++v) npt_prow[nslot[v]] = (unsigned char)nrow[v];
       npt_n_rows = (n_rows + 1) & ~1;
       // compact direction table: one row per node that carries slot terms
-      npt_wslot.assign(NPT_MAXN, 255);
+      npt_wslot.assign(NPT_ROWS, 255);
       int n_wrows = 0;
       npt_term_sync = 0;
       std::vector<int> wslot_of_node(N, 255);
-      for (int t = 0; t < NPT_MAXN; ++t)
+      for (int t = 0; t < NPT_ROWS; ++t)
         if (npt_node_of_row[t] >= 0 && sdeg[npt_node_of_row[t]]) {
           wslot_of_node[npt_node_of_row[t]] = n_wrows;
           npt_wslot[t] = (unsigned char)n_wrows++;
@@ -1890,7 +1911,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
         for (size_t q = 0; q < npt_term_rec.size(); ++q)   // padding: rows 0 / 0, kind 0, the zero direction row
           npt_term_rec[q] = ((uint32_t)n_wrows << 18) | ((uint32_t)n_wrows << 25);
         struct GEnt { int other, kind, slot, neg; };
-        std::vector<std::vector<GEnt>> glist(NPT_MAXN);
+        std::vector<std::vector<GEnt>> glist(NPT_ROWS);
         for (int q = 0; q < Tn; ++q) {
           const int t = nc_term[q], i = d->term_i[t], j = d->term_j[t], kind = d->term_kind[t];
           const int ri = nrow[i], rj = nrow[j];
@@ -1902,7 +1923,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
           glist[nslot[j]].push_back({i, kind, q, 1});
         }
         int deg[2] = {0, 0};
-        for (int r = 0; r < NPT_MAXN; ++r)
+        for (int r = 0; r < NPT_ROWS; ++r)
           std::stable_sort(glist[r].begin(), glist[r].end(), [](const GEnt &a, const GEnt &b) {
             return a.other != b.other ? a.other < b.other : a.kind < b.kind;
           });
@@ -1912,7 +1933,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
           hlp.assign(own.begin() + keep, own.end());
           own.resize(keep);
         }
-        for (int r = 0; r < NPT_MAXN; ++r) {
+        for (int r = 0; r < NPT_ROWS; ++r) {
           const int sl = NSn == 1 ? 0 : (r & 1);
           deg[sl] = std::max(deg[sl], (int)glist[r].size());
         }
@@ -1921,14 +1942,14 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
         npt_lists_fit = deg[0] + deg[1] <= 16;      // NptCtx::NG packed words
         const unsigned short pad = (unsigned short)(2 * Tn);
         npt_gather.assign((size_t)std::max(1, deg[0] + deg[1]) * NTn, pad);
-        for (int r = 0; r < NPT_MAXN; ++r) {
+        for (int r = 0; r < NPT_ROWS; ++r) {
           const int thr = r / NSn, sl = r % NSn;
           for (size_t e = 0; e < glist[r].size(); ++e)
             npt_gather[(size_t)(sl ? deg[0] + (int)e : (int)e) * NTn + thr] =
                 (unsigned short)((glist[r][e].slot << 1) | glist[r][e].neg);
         }
         npt_pair_term.clear();
-        std::vector<int> node_at_row(NPT_MAXN, 0);
+        std::vector<int> node_at_row(NPT_ROWS, 0);
         for (int v = 0; v < N; ++v) node_at_row[nrow[v]] = v;
         for (int a = 0; a < n_clq; ++a)
           for (int b = a + 1; b < n_clq; ++b)
@@ -1956,6 +1977,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     }
   }
   }
+  if (meta.empty()) meta.assign(1, 0u);      // (graphs beyond 128 nodes: no slot table of the 512-thread kernels)
   gik_template *t = new gik_template();
   t->is_block = is_block;
   t->SL = SL;
@@ -2163,7 +2185,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
     t->nt.n_terms = npt_n_terms;
     t->nt.term_sync = npt_term_sync;
     for (const NptVariant &v : kNptVariants)
-      if (v.TL == npt_TL && v.NW == (npt_two_waves ? 2 : 1)) t->npt_variant = &v;
+      if (v.TL == npt_TL && v.NW == npt_NW) t->npt_variant = &v;
     t->npt_smem = t->npt_variant->lds(t->nt.n_pairs, npt_n_wrows, npt_n_rows, npt_n_terms);
     const void *fns[2] = {(const void *)t->npt_variant->solve, (const void *)t->npt_variant->kat};
     int occ_npt = 0;
@@ -2181,6 +2203,11 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
       t->is_npt = true;
       t->npt_waves_per_cu = std::max(1, std::min(occ_npt, 4));   // problems (workgroups) per CU
     }
+  }
+  if (big && !t->is_npt) {
+    gik_template_destroy(t);
+    return fail("graphs of more than 128 nodes need the node-per-lane kernel: at most 256 terms outside the rigid clique "
+                "(16 per node), at most 127 nodes that carry such terms");
   }
   if ((t->dbg & 32) && t->is_npt)
     fprintf(stderr, "  node-per-lane kernel: %d wavefront(s) per problem, TL=%d, %d slot terms (sync %d), %d direction rows, gather lists %d + %d, "
@@ -2545,7 +2572,14 @@ static int launch_kat(const gik_template *t, int mode, const double *d_Y, const 
                        (hipStream_t)stream, a);
   } else if (t->is_npt) {
     a.nt = t->nt;
+    // (graphs beyond 128 nodes: a stream-ordered scratch for the clique target triangles of this call's workgroups;
+    //  these one-call-at-a-time entry points are the known-answer interface, not the batch path)
+    const size_t ctg = t->npt_variant->ctg(t->nt.n_pairs) * sizeof(double) * (size_t)B;
+    void *ws = nullptr;
+    if (ctg) HIP_OK(hipMallocAsync(&ws, ctg, (hipStream_t)stream));
+    a.npt_ctg_ws = static_cast<double *>(ws);
     hipLaunchKernelGGL(t->npt_variant->kat, dim3(B), dim3(WAVE * t->npt_variant->NW), t->npt_smem, (hipStream_t)stream, a);
+    if (ws) HIP_OK(hipFreeAsync(ws, (hipStream_t)stream));
   } else if (t->is_block) {
     if (t->K == 3)
       hipLaunchKernelGGL(kat_block_kernel<3>, dim3(B), dim3(BLOCK_NT), t->smem_bytes,
@@ -2733,8 +2767,11 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
                    (!t->hess_per_edge || t->variant->solve_strict_mig) && t->p.theta == 1.0 &&
                    wpc > 4 && B > grid && !(a.dbg & (1 | 512));
   gik_template::SliceWs *sw = nullptr;
-  if (slice > 0 || mig) {
-    const size_t cap = mig ? (size_t)B + (size_t)grid + 64 : (size_t)B * (size_t)(t->p.maxiter / slice + 1);
+  // graphs beyond 128 nodes (node-per-lane kernel on four wavefronts): the clique's target triangle of every resident
+  // workgroup lives in global memory -- a region of the same pooled workspace
+  const size_t ctg_bytes = t->is_npt ? t->npt_variant->ctg(t->nt.n_pairs) * sizeof(double) * (size_t)grid : 0;
+  if (slice > 0 || mig || ctg_bytes) {
+    const size_t cap = mig ? (size_t)B + (size_t)grid + 64 : (slice > 0 ? (size_t)B * (size_t)(t->p.maxiter / slice + 1) : 0);
     // wavefront kernel: round-robin slicing (slice length: the handle's wave_slice_its)
     // Slice length grows with the queue: 256 iterations up to 8 problems per wave, 4 x that from 32 per wave on.
     // A hand-over moves ~4.5 KB through HBM (point, state, the targets re-read; PMC, round 3: 624 MB per 65536-goal
@@ -2755,7 +2792,8 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     const size_t off_simd = 32, off_seq = off_simd + (mig ? sizeof(int) * MIG_SIMDS : 0), off_ids = off_seq + cap * 4,
                  off_state = (off_ids + cap * 4 + 15) & ~(size_t)15,
                  off_yseq = off_state + (((size_t)B * sizeof(SliceState) + 15) & ~(size_t)15), off_yids = off_yseq + ycap * 4;
-    const size_t bytes = off_yids + ycap * 4;
+    const size_t off_ctg = (off_yids + ycap * 4 + 63) & ~(size_t)63;
+    const size_t bytes = off_ctg + ctg_bytes;
     sw = &mt->slice_ws[take(mt->slice_ws, mt->next_slice, (unsigned)t->slice_pool)];
     release.sw = sw;
     if (!sw->done && hipEventCreateWithFlags(&sw->done, hipEventDisableTiming) != hipSuccess)
@@ -2785,9 +2823,10 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
     a.y_seq = reinterpret_cast<unsigned int *>(base + off_yseq);
     a.y_ids = reinterpret_cast<int *>(base + off_yids);
     a.y_cap = (unsigned int)ycap;
+    a.npt_ctg_ws = ctg_bytes ? reinterpret_cast<double *>(base + off_ctg) : nullptr;
     if (mig) { a.slice_its = wslice; a.slice_cycles = t->wave_slice_cycles; }
     HIP_OK(hipMemsetAsync(base, 0, off_seq, (hipStream_t)stream));
-    HIP_OK(hipMemsetAsync(a.q_seq, 0xFF, cap * 4, (hipStream_t)stream));
+    if (cap) HIP_OK(hipMemsetAsync(a.q_seq, 0xFF, cap * 4, (hipStream_t)stream));
     if (mig || t->is_npt) HIP_OK(hipMemsetAsync(a.q_state, 0, (size_t)B * sizeof(SliceState), (hipStream_t)stream));
     if (ycap) HIP_OK(hipMemsetAsync(a.y_seq, 0, ycap * 4, (hipStream_t)stream));
   }
