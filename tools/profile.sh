@@ -5,7 +5,7 @@
 # Results land under gpurun_out/prof_<tag>/; tools/summarize_prof.py copies the summaries worth keeping
 # to profiles/.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r04}; shift
+TAG=${1:-r05}; shift
 P=$R/gpurun_out/prof_$TAG
 mkdir -p "$P"
 cd /tmp && export TMPDIR=/tmp
