@@ -900,15 +900,14 @@ __device__ inline void compress_to_basis_blk(double *A, int N, int r, const doub
   __syncthreads();
 }
 
-// eigenvectors of B from those of M: V[i][k] = sum_m Q[i][m] W[m][k] (k < r), zero columns beyond; the
-// eigenvalues stay on A's diagonal (zeros beyond r)
+// eigenvectors of B from those of M: V[i][k] = sum_m Q[i][m] W[m][k] (k < r); the columns beyond are zero and are
+// NOT written; the eigenvalues stay on A's diagonal (zeros beyond r)
 __device__ inline void expand_from_basis_blk(double *A, double *V, int N, int r, const double *Qt, const double *W,
                                              int tid) {
-  for (int e = tid; e < N * N; e += PREP_NT) {      // e = k * N + i: consecutive threads take consecutive rows i
-    const int k = e / N, i = e - k * N;
+  for (int e = tid; e < r * N; e += PREP_NT) {      // e = k * N + i: consecutive threads take consecutive rows i
+    const int k = e / N, i = e - k * N;                // (columns k >= r are zero and are not stored: the caller's nc)
     double s = 0.0;
-    if (k < r)
-      for (int m = 0; m < r; ++m) s = fma(Qt[m * N + i], W[m * N + k], s);
+    for (int m = 0; m < r; ++m) s = fma(Qt[m * N + i], W[m * N + k], s);
     V[i * N + k] = s;
   }
   if (tid >= r && tid < N) A[tid * N + tid] = 0.0;
@@ -925,7 +924,7 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
   __shared__ double gd[2 * PREP_MAXA + 16];     // (several end effectors: checked at attach)
   __shared__ double cs[2 * (PREP_MAXN / 2)];
   __shared__ double ev[PREP_MAXN], sg[PREP_MAXN], red[PREP_NT / 64];
-  __shared__ int pq[PREP_MAXN / 2], rk[PREP_MAXN];
+  __shared__ int pq[PREP_MAXN / 2], rk[PREP_MAXN], cinv[PREP_MAXN];
   __shared__ double dl[PREP_PC * PREP_MAXN];    // edge differences of PREP_PC pairs; Jacobi rotation log
   static_assert(JLOG_DOUBLES <= PREP_PC * PREP_MAXN, "the rotation log shares the scatter phase's tile buffer");
   const PipeConst &pc = a.pc;
@@ -941,15 +940,20 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
   double *V = L + 2 * NN;                        // eigenvectors / temp
   double *X = V + NN;                            // MDS factor
   const int D = K + 1;
+  // The LOWER table differs between goals in the goal-node entries only, and those sit at the same places for every
+  // goal: this workgroup's copy is written ONCE per launch and patched per goal (until round 5 it was rewritten
+  // whole for every goal, and its buffer then reused as scratch: 107 KB of stores per table-scene goal).
+  for (int e = tid; e < NN; e += PREP_NT) {
+    const double lo = pc.base_lower[e];
+    L[e] = ((e / N) == (e % N)) ? 0.0 : (lo == lo ? lo : -INFINITY);
+  }
 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     const double *Tg = a.T_goal + (size_t)b * D * D * pc.n_ee;
     const int n_gd = 2 * pc.n_ee * pc.n_anchor + pc.n_gg;
     for (int e = tid; e < NN; e += PREP_NT) {
-      const double lo = pc.base_lower[e], up = pc.base_upper[e];
-      const bool diag = (e / N) == (e % N);
-      U[e] = diag ? 0.0 : (up == up ? up : INFINITY);
-      L[e] = diag ? 0.0 : (lo == lo ? lo : -INFINITY);
+      const double up = pc.base_upper[e];
+      U[e] = ((e / N) == (e % N)) ? 0.0 : (up == up ? up : INFINITY);
     }
     __syncthreads();
     for (int idx = tid; idx < n_gd; idx += PREP_NT) {
@@ -980,33 +984,38 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
 #ifdef GIK_DEV
     if (a.stop_phase == 2) continue;
 #endif
-    for (int e = tid; e < NN; e += PREP_NT) {  // A[u][b] = max_a (L[a][b] - U[u][a])
-      const int u = e / N, bb = e - u * N;
-      double best = -INFINITY;
-      for (int q = 0; q < N; ++q) best = fmax(best, L[q * N + bb] - U[u * N + q]);
-      A1[e] = best;
+    // A1[u][b] = max_a (L[a][b] - ub[u][a]), then lb[u][v] = max(0, max_q A1[u][q] - ub[q][v]) and, from it,
+    // D_rand = (lb + 0.9 (ub - lb))^2 -- by BLOCKS OF ROWS u: the rows of the max-plus intermediate live in the LDS
+    // tile buffer (4096 doubles: 35 rows at N = 116) and never reach the slab, and lb goes straight into D_rand
+    // (round 5: two N x N stores and loads per goal less; same operations per element; the diagnostics still get lb)
+    {
+      const int RB = (PREP_PC * PREP_MAXN) / N;      // rows per block
+      for (int u0 = 0; u0 < N; u0 += RB) {
+        const int nr = min(RB, N - u0);
+        for (int idx = tid; idx < nr * N; idx += PREP_NT) {
+          const int ur = idx / N, bb = idx - ur * N, u = u0 + ur;
+          double best = -INFINITY;
+          for (int q = 0; q < N; ++q) best = fmax(best, L[q * N + bb] - U[u * N + q]);
+          dl[idx] = best;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nr * N; idx += PREP_NT) {
+          const int ur = idx / N, v = idx - ur * N, e = (u0 + ur) * N + v;
+          double best = 0.0;
+          for (int q = 0; q < N; ++q) best = fmax(best, dl[ur * N + q] - U[q * N + v]);
+          if (a.dbg_lb) {
+            a.dbg_lb[(size_t)b * NN + e] = best;
+            a.dbg_ub[(size_t)b * NN + e] = U[e];
+          }
+          const double d = best + 0.9 * (U[e] - best);
+          X[e] = d * d;
+        }
+        __syncthreads();
+      }
     }
-    __syncthreads();
-    for (int e = tid; e < NN; e += PREP_NT) {  // V[u][v] = lb
-      const int u = e / N, v = e - u * N;
-      double best = 0.0;
-      for (int q = 0; q < N; ++q) best = fmax(best, A1[u * N + q] - U[q * N + v]);
-      V[e] = best;
-    }
-    __syncthreads();
 #ifdef GIK_DEV
     if (a.stop_phase == 3) continue;
 #endif
-    if (a.dbg_lb)
-      for (int e = tid; e < NN; e += PREP_NT) {
-        a.dbg_lb[(size_t)b * NN + e] = V[e];
-        a.dbg_ub[(size_t)b * NN + e] = U[e];
-      }
-    // ---- generate_initialization: D_rand = (lb + 0.9 (ub - lb))^2, Gram = -1/2 J D J
-    for (int e = tid; e < NN; e += PREP_NT) {
-      const double lbv = V[e], d = lbv + 0.9 * (U[e] - lbv);
-      X[e] = d * d;
-    }
     __syncthreads();
     if (tid < N) {
       double s = 0.0;
@@ -1020,28 +1029,36 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
     for (int e = tid; e < NN; e += PREP_NT) {
       const int i = e / N, j = e - i * N;
       A[e] = -0.5 * (X[e] - ev[i] - ev[j] + mean);
-      V[e] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
 #ifdef GIK_DEV
     if (a.stop_phase == 4) continue;
 #endif
+    // nc: columns of V / X that are STORED from here on.  With the range compression only the r eigenvectors of the
+    // range exist -- the other N - r columns are exact zeros -- and round 5 no longer writes, scales, reads or clears
+    // them (four N x N stores and three loads per goal): whoever reads X asks cinv[] < nc first.
+    int nc = N;
     {
       int rnk = -1;
       if (A_LDS && N >= PREP_COMPRESS_MIN_N && !a.no_compress) {
         // (global buffers free at this point: the slab's copy of the upper bounds Ug -- they live in LDS --, the
-        // lower bounds L, the max-plus intermediate A1, X; graphs whose work matrix itself sits in the slab,
-        // N > 123, keep the full decomposition)
-        double *Bc = A1, *Qt = X, *Tt = L, *W = Ug;
+        // work-matrix slot A1, V and X; NOT the lower-bound table L, which stays for the next goal; graphs whose
+        // work matrix itself sits in the slab, N > 123, keep the full decomposition)
+        double *Bc = A1, *Qt = X, *Tt = V, *W = Ug;       // (V is written by expand_from_basis_blk, after Tt's last use)
         rnk = range_basis_blk(A, N, Bc, Qt, ev, sg, cs, red, tid);
         if (rnk >= 0) {
           compress_to_basis_blk(A, N, rnk, Bc, Qt, Tt, W, tid);
           if (rnk > 1) jacobi_blk(A, W, N, a.sweeps, cs, pq, red, tid, rnk, dl);
           __syncthreads();
           expand_from_basis_blk(A, V, N, rnk, Qt, W, tid);
+          nc = rnk;
         }
       }
-      if (rnk < 0) jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid, -1, dl);
+      if (rnk < 0) {
+        for (int e = tid; e < NN; e += PREP_NT) V[e] = ((e / N) == (e % N)) ? 1.0 : 0.0;
+        __syncthreads();
+        jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid, -1, dl);
+      }
     }
 #ifdef GIK_DEV
     if (a.stop_phase == 5) continue;
@@ -1054,25 +1071,28 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
     if (tid < N) {
       rk[tid] = desc_rank(ev, N, tid);
       double big = 0.0, sgn = 1.0;
-      for (int r = 0; r < N; ++r) {
-        const double v = V[r * N + tid];
-        if (fabs(v) > big) {
-          big = fabs(v);
-          sgn = v < 0.0 ? -1.0 : 1.0;
+      if (tid < nc)                      // (a column that is not stored is zero: no entry, sign +)
+        for (int r = 0; r < N; ++r) {
+          const double v = V[r * N + tid];
+          if (fabs(v) > big) {
+            big = fabs(v);
+            sgn = v < 0.0 ? -1.0 : 1.0;
+          }
         }
-      }
       sg[tid] = sgn * sqrt(fmax(ev[tid], 0.0));
     }
     __syncthreads();
-    for (int e = tid; e < NN; e += PREP_NT) {
-      const int r = e / N, c = e - r * N;
-      X[r * N + rk[c]] = V[e] * sg[c];
+    if (tid < N) cinv[rk[tid]] = tid;    // column j of X came from eigenvector cinv[j]: stored iff cinv[j] < nc
+    for (int e = tid; e < N * nc; e += PREP_NT) {
+      const int r = e / nc, c = e - r * nc;
+      X[r * N + rk[c]] = V[r * N + c] * sg[c];
     }
     __syncthreads();
     // ---- MDS(): K = #eigenvalues > eps of the symmetric matrix read from the LOWER triangle of x
     for (int e = tid; e < NN; e += PREP_NT) {
       const int i = e / N, j = e - i * N;
-      A[e] = (i >= j) ? X[i * N + j] : X[j * N + i];
+      const int rr = i >= j ? i : j, cj = i >= j ? j : i;
+      A[e] = cinv[cj] < nc ? X[rr * N + cj] : 0.0;
     }
     __syncthreads();
 #ifdef GIK_DEV
@@ -1085,7 +1105,8 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       __syncthreads();
       for (int e = tid; e < NN; e += PREP_NT) {
         const int i = e / N, j = e - i * N;
-        A[e] = (i >= j) ? X[i * N + j] : X[j * N + i];
+        const int rr = i >= j ? i : j, cj = i >= j ? j : i;
+        A[e] = cinv[cj] < nc ? X[rr * N + cj] : 0.0;
       }
       __syncthreads();
     }
@@ -1095,12 +1116,7 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
 #ifdef GIK_DEV
     if (a.stop_phase == 7) continue;
 #endif
-    // ---- linear_projection (dgp.py:174-183)
-    for (int e = tid; e < NN; e += PREP_NT) {
-      const int c = e % N;
-      if (c >= Kc) X[e] = 0.0;
-    }
-    __syncthreads();
+    // ---- linear_projection (dgp.py:174-183): X[:, Kc:] = 0 -- not cleared in memory: every read below stops at Kc
     {
       // S[r][c] = sum_p d_p[r] d_p[c], d_p = X[i_p] - X[j_p]: 5604 pairs x Kc^2 at N = 116.  The
       // edge differences of 32 pairs at a time are staged in LDS; a thread owns row r = tid / 4 and
@@ -1124,7 +1140,7 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       double *XL = A;
       for (int e = tid; e < N * kw; e += PREP_NT) {
         const int i = e / kw, c = e - i * kw;
-        XL[e] = c < Kc ? X[i * N + c] : 0.0;
+        XL[e] = (c < Kc && cinv[c] < nc) ? X[i * N + c] : 0.0;
       }
       __syncthreads();
       for (int p0 = 0; p0 < pc.n_pairs; p0 += PREP_PC) {
@@ -1156,13 +1172,19 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
         const int c = c0 + 4 * q;
         if (r < N && c < N) A[r * N + c] = 2.0 * acc[q];  // the reference sums both (i,j) and (j,i)
       }
-      for (int e = tid; e < NN; e += PREP_NT) V[e] = ((e / N) == (e % N)) ? 1.0 : 0.0;
+    }
+    // the K x K Jacobi touches the leading n2 x n2 block of V only (outside it V is the identity, implicitly)
+    const int n2 = Kc > 1 ? Kc : 2;
+    __syncthreads();
+    for (int e = tid; e < n2 * n2; e += PREP_NT) {
+      const int i = e / n2, j = e - i * n2;
+      V[i * N + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
 #ifdef GIK_DEV
     if (a.stop_phase == 8) continue;
 #endif
-    jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid, Kc > 1 ? Kc : 2, dl);
+    jacobi_blk(A, V, N, a.sweeps, cs, pq, red, tid, n2, dl);
     __syncthreads();
 #ifdef GIK_DEV
     if (a.stop_phase == 9) continue;
@@ -1173,23 +1195,27 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
     if (tid < N) {
       rk[tid] = desc_rank(ev, N, tid);
       double big = 0.0, sgn = 1.0;
-      for (int r = 0; r < N; ++r) {
-        const double v = V[r * N + tid];
-        if (fabs(v) > big) {
-          big = fabs(v);
-          sgn = v < 0.0 ? -1.0 : 1.0;
+      if (tid < n2)                      // (outside the block column tid of V is e_tid: sign +)
+        for (int r = 0; r < n2; ++r) {
+          const double v = V[r * N + tid];
+          if (fabs(v) > big) {
+            big = fabs(v);
+            sgn = v < 0.0 ? -1.0 : 1.0;
+          }
         }
-      }
       sg[tid] = sgn;
     }
     __syncthreads();
-    if (tid < N * K) {   // N * K <= 384
-      const int r = tid / K, dcol = tid - r * K;
+    for (int t = tid; t < N * K; t += PREP_NT) {
+      const int r = t / K, dcol = t - r * K;
       int col = 0;
       for (int c = 0; c < N; ++c) col = (rk[c] == dcol) ? c : col;
+      // Y = X[:, :Kc] V[:Kc, col]: the columns of X beyond Kc are zero, V is the identity outside its n2 x n2 block
       double s = 0.0;
-      for (int c = 0; c < N; ++c) s += X[r * N + c] * V[c * N + col];
-      a.Y_init[(size_t)b * N * K + tid] = s * sg[col];
+      if (col < n2)
+        for (int c = 0; c < Kc; ++c)
+          if (cinv[c] < nc) s += X[r * N + c] * V[c * N + col];
+      a.Y_init[(size_t)b * N * K + t] = s * sg[col];
     }
     __syncthreads();
   }
