@@ -50,7 +50,8 @@ enum { GIK_TERM_EQ = 1, GIK_TERM_LOWER = 2, GIK_TERM_UPPER = 3 };
  * `inds` (row-major upper triangle), and which of omega / psi_L / psi_U is set on each.   */
 typedef struct {
   int32_t abi_version;   /* GIK_ABI_VERSION                                               */
-  int32_t N;             /* number of graph nodes (rows of Y)                             */
+  int32_t N;             /* number of graph nodes (rows of Y): 2 .. 255; beyond 128 only k = 3, TrustRegions,
+                            theta = 1 graphs with at most 256 terms outside a rigid clique (obstacle scenes)  */
   int32_t k;             /* embedding dimension: 3 (revolute) or 2 (planar)               */
   int32_t n_terms;       /* number of residual terms T                                    */
   const int32_t *term_i; /* [T] first node index  (i < j)                                 */
@@ -134,8 +135,13 @@ enum {
  *     are chained by an event (they serialise; results are unaffected);
  *   - anchored templates: the event pair read by gik_anchored_last_solve_ms (diagnostic; with
  *     concurrent callers it reports whichever call recorded last).
- * Results never depend on any of it.  Destroying a handle while calls on it are in flight is
- * undefined; synchronise first.                                                                  */
+ * Results never depend on any of it.  ONE thing about a call does select arithmetic: planar graphs of at most 16
+ * nodes run four problems to a wavefront (rtr_quad_kernel: the k = 2 projector by substitution, inner products summed
+ * per node first) in batches of at least 12 problems per CU and one problem per wavefront below that, so the same goal
+ * can come back with different last bits (x agrees to ~1e-9, iteration counts on 100 %, inner_total on 99.3 % of
+ * 65536 goals) depending on how many goals share the call -- or, with solve_batch_sharded, on the world size.
+ * debug_flags 16384 / 8192 pin the four-problem / one-problem kernel at every batch size.  Destroying a handle while
+ * calls on it are in flight is undefined; synchronise first.                                          */
 typedef struct gik_template gik_template;
 
 /* Per-problem solver statistics (final_values of the reference's optlog + counters). */
@@ -208,10 +214,12 @@ typedef struct {
   int32_t prepare_is_block;    /* workgroup-per-goal prepare kernel                                 */
   int32_t node_per_lane;       /* != 0: an is_block graph solved by the node-per-lane kernel instead of the
                                   512-thread workgroup kernel; the value is its wavefronts per problem (2: one
-                                  node per lane, 1: two nodes per lane)                                   */
+                                  node per lane, 1: two nodes per lane, 4: one node per lane, graphs of 129 .. 255
+                                  nodes -- the only kernel that takes them)                               */
   int32_t problems_per_wave;   /* 4: planar graph (k = 2, <= 16 nodes, <= 6 terms per node) whose trust-region
                                   solves run four problems to a wavefront (rtr_quad_kernel) in batches of at
-                                  least 12 problems per CU; else 1 (0: block) */
+                                  least 12 problems per CU (smaller batches: one per wavefront, see the note on
+                                  the handle above); else 1 (0: block) */
   int32_t goals_per_wave;      /* prepare kernel: 4 = graph of at most 16 nodes, four goals to a wavefront
                                   (prep_quad_kernel); 1 = one (prep_wave_kernel); 0 = workgroup per goal / no pipeline */
   int32_t hessian_form;        /* GIK_HESS_* in effect on the wavefront kernel (GIK_HESS_COLUMN elsewhere)          */
