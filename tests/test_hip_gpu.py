@@ -1799,7 +1799,9 @@ def test_c_abi_error_behaviour(torch_cuda):
     refused(L.gik_template_create(C.byref(desc(abi_version=_ffi.ABI_VERSION - 1)), C.byref(h)), "ABI")
     refused(L.gik_template_create(C.byref(desc(k=4)), C.byref(h)), "k must be")
     refused(L.gik_template_create(C.byref(desc(N=1)), C.byref(h)), "N must be")
-    refused(L.gik_template_create(C.byref(desc(N=129)), C.byref(h)), "N must be")
+    refused(L.gik_template_create(C.byref(desc(N=256)), C.byref(h)), "N must be")      # (round 5: up to 255)
+    refused(L.gik_template_create(C.byref(desc(N=129, k=2)), C.byref(h)), "128 nodes")  # beyond 128: 3-D TrustRegions only
+    refused(L.gik_template_create(C.byref(desc(hessian_form=3)), C.byref(h)), "hessian_form")
     refused(L.gik_template_create(C.byref(desc(n_terms=0)), C.byref(h)), "n_terms")
     refused(L.gik_template_create(C.byref(desc(solver=7)), C.byref(h)), "solver")
     refused(L.gik_template_create(C.byref(desc(clique_closed_form=9)), C.byref(h)), "clique_closed_form")
