@@ -361,13 +361,21 @@ def _bench(cmd_prefix, *extra):
     return json.loads(lines[0])
 
 
+def _free_port():
+    """A rendezvous port nobody holds (a fixed one may still be in TIME_WAIT from the previous run)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_rccl_gather_under_torchrun(torch_cuda):
     """`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 --backend nccl`: RCCL comes up, the
     barrier / max-over-ranks / all_gather path runs on the device, and the gathered per-problem
     table equals (sha256) the table of a plain single-process run without a process group -- the
     only RCCL coverage a one-GPU lease allows."""
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
-                "--master-addr", "127.0.0.1", "--master-port", "29547"]
+                "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
     a = _bench(launcher, "--backend", "nccl", "--batch", "256")
     b = _bench([sys.executable], "--batch", "256")
     assert a["gather"]["backend"] == "nccl" and b["gather"]["backend"] is None
@@ -422,7 +430,7 @@ def test_solve_batch_sharded_over_rccl(torch_cuda, tmp_path):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
-           "--master-addr", "127.0.0.1", "--master-port", "29549", str(script)]
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, env=env, timeout=600, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     got = dict(np.load(out))
