@@ -20,7 +20,8 @@
 // "the scalar of the lane g places further on in the triple" lands in a register with a compile-time index.
 // cost() and commit() work from natural-order rows as well: the squared distance of a term is then one value, bit
 // for bit, in all six lanes that hold it (the column form needs a DPP exchange for that, WaveCtx::commit).
-// Per product: 15 DS instructions instead of 10, ~90 vector instructions instead of 48 (measured price: DESIGN 4.1).
+// Per tCG step: 220 instructions instead of 188 (18 DS instead of 10, 32 DPP moves instead of 20); measured price:
+// c2 -8.0 %, c4 -8.9 %.
 #pragma once
 
 #include "gik_wave.hip.h"
@@ -39,8 +40,11 @@ struct WaveCtxStrict : WaveCtx<3, MAXDEG, false> {
   static constexpr bool AGE_PRIORITY = Base::AGE_PRIORITY;
 
   int natoff[LS];        // row of the neighbour of local slot sigma in tile 0 (natural order), double index
-  int recidx[LS];        // its slot record (node slot * 64 + lane), -1: padding
-  double ysc[LS];        // 2 a y_c      (this lane's component of the term's difference vector)
+  double ysc[NSH];       // 2 a y_c      (this lane's component of the term's difference vector), own slots (g = 0)
+  // ... and of the other lanes' slots, one coefficient per DIRECTION the scalar can arrive from -- lane + 1 (P: c = 0,
+  // 1), lane - 2 (S: c = 2) for g = 1; lane + 2 (R: c = 0), lane - 1 (Q: c = 1, 2) for g = 2 -- zero where the
+  // direction is not this lane's: the product multiplies all four shifted copies instead of bit-selecting two
+  double ysP[NSH], ysS[NSH], ysR[NSH], ysQ[NSH];
   double cc[LS];         // 2 c
   double ysn[NSH][3];    // 2 a y, natural order, of the slots whose scalar this lane forms (g = 0)
 
@@ -54,16 +58,23 @@ struct WaveCtxStrict : WaveCtx<3, MAXDEG, false> {
       const int s = h + 3 * k;
       const bool real = s < MAXDEG;
       natoff[sg] = real ? meta_j(this->sh_meta[(real ? s : 0) * WAVE + this->lane]) * RS : this->nat_off;
-      recidx[sg] = real ? s * WAVE + this->lane : -1;
-      ysc[sg] = cc[sg] = 0.0;
+      cc[sg] = 0.0;
     }
 #pragma unroll
-    for (int k = 0; k < NSH; ++k) ysn[k][0] = ysn[k][1] = ysn[k][2] = 0.0;
+    for (int k = 0; k < NSH; ++k) ysc[k] = ysP[k] = ysS[k] = ysR[k] = ysQ[k] = ysn[k][0] = ysn[k][1] = ysn[k][2] = 0.0;
   }
 
+  // slot record of local slot sg (its index is recomputed from the component where it is used -- once per outer
+  // iteration -- instead of held in a register per slot across the tCG loop)
   __device__ inline SlotRec record(int sg) const {
-    SlotRec r = this->sh_rec[recidx[sg] < 0 ? this->lane : recidx[sg]];
-    if (recidx[sg] < 0) {      // padding: clamp(., 0, 0) = 0, never active
+    int c = this->comp;
+    asm volatile("" : "+v"(c));
+    int h = c + sg / NSH;
+    h = h >= 3 ? h - 3 : h;
+    const int s = h + 3 * (sg % NSH);
+    const bool real = s < MAXDEG;
+    SlotRec r = this->sh_rec[(real ? s : 0) * WAVE + this->lane];
+    if (!real) {               // padding: clamp(., 0, 0) = 0, never active
       r.tg = 0.0;
       r.lo = r.hi = 0.0f;
     }
@@ -106,7 +117,16 @@ struct WaveCtxStrict : WaveCtx<3, MAXDEG, false> {
       const bool act = (rc.lo * rc.hi < 0.0f) || (cl != 0.0);  // (see WaveCtx::commit)
       const double c = -cl;
       const double yc = own_comp(y0, y1, y2);
-      ysc[sg] = act ? yc + yc : 0.0;
+      const double ys = act ? yc + yc : 0.0;
+      if (sg < NSH) {
+        ysc[sg] = ys;
+      } else if (sg < 2 * NSH) {        // holder (c + 1) % 3: its scalar arrives from lane + 1 (c = 0, 1) or lane - 2 (c = 2)
+        ysP[sg - NSH] = this->comp != 2 ? ys : 0.0;
+        ysS[sg - NSH] = this->comp == 2 ? ys : 0.0;
+      } else {                          // holder (c + 2) % 3: from lane + 2 (c = 0) or lane - 1 (c = 1, 2)
+        ysR[sg - 2 * NSH] = this->comp == 0 ? ys : 0.0;
+        ysQ[sg - 2 * NSH] = this->comp != 0 ? ys : 0.0;
+      }
       cc[sg] = c + c;
       G = fma(c, yc, G);
       if (sg < NSH) {      // g = 0: this lane forms the slot's scalar
@@ -127,26 +147,27 @@ struct WaveCtxStrict : WaveCtx<3, MAXDEG, false> {
     Row<3> rw[NSH];
 #pragma unroll
     for (int k = 0; k < NSH; ++k) rw[k] = this->read_row(natoff[k]);
-    double wj[LS - NSH];
+    // (the own component of the whole rows as well: one more 8-byte read per slot instead of a two-level bit-select
+    //  on the row -- the vector ALU, not the LDS pipe, is what this kernel runs out of)
+    double wj[LS];
 #pragma unroll
-    for (int sg = NSH; sg < LS; ++sg) wj[sg - NSH] = tile_c[natoff[sg]];
+    for (int sg = 0; sg < LS; ++sg) wj[sg] = tile_c[natoff[sg]];
     // the scalars of this lane's slots, natural order (both ends of an edge: the same bits)
     double sc[NSH], H = 0.0;
 #pragma unroll
     for (int k = 0; k < NSH; ++k) {
       const double u0 = wn.v[0] - rw[k].v[0], u1 = wn.v[1] - rw[k].v[1], u2 = wn.v[2] - rw[k].v[2];
       sc[k] = fma(ysn[k][2], u2, fma(ysn[k][1], u1, ysn[k][0] * u0));
-      H = fma(sc[k], ysc[k], fma(cc[k], own_comp(u0, u1, u2), H));
+      H = fma(sc[k], ysc[k], fma(cc[k], W - wj[k], H));
     }
     // the other two lanes' scalars: lane c needs those of the lanes one and two places on in its triple
 #pragma unroll
     for (int k = 0; k < NSH; ++k) {
       const double dn1 = wave_shl<1>(sc[k]), dn2 = wave_shl<1>(dn1);     // from lane + 1, + 2
       const double up1 = wave_shr<1>(sc[k]), up2 = wave_shr<1>(up1);     // from lane - 1, - 2
-      const double s1 = bit_select(this->comp == 2, up2, dn1);           // holder (c + 1) % 3
-      const double s2 = bit_select(this->comp == 0, dn2, up1);           // holder (c + 2) % 3
-      H = fma(s1, ysc[NSH + k], fma(cc[NSH + k], W - wj[k], H));
-      H = fma(s2, ysc[2 * NSH + k], fma(cc[2 * NSH + k], W - wj[NSH + k], H));
+      // holder (c + 1) % 3: dn1 or up2; holder (c + 2) % 3: dn2 or up1 -- the coefficient of the wrong one is zero
+      H = fma(dn1, ysP[k], fma(up2, ysS[k], fma(cc[NSH + k], W - wj[NSH + k], H)));
+      H = fma(dn2, ysR[k], fma(up1, ysQ[k], fma(cc[2 * NSH + k], W - wj[2 * NSH + k], H)));
     }
     return H;
   }

@@ -113,8 +113,8 @@ typedef struct {
    * s = y . (W_i - W_j) of costs.py:186-203 is never formed, and truncated CG then needs ~7 % more Hessian products
    * than the reference's arithmetic from the same start points (7-DOF arms end 8e-3 rad from the reference in the
    * median instead of 2.5e-3; both inside the band the reference's own two code paths span).  GIK_HESS_PER_EDGE:
-   * s once per edge, t = 2 s a y + c w as written -- the form every other kernel of the library uses -- at ~25 % more
-   * time per product (measured price: DESIGN.md 4.1).  Graphs that run on other kernels accept either value.  */
+   * s once per edge, t = 2 s a y + c w as written -- the form every other kernel of the library uses -- at ~14 % more
+   * time per product, 8-9 % of the throughput (measured: DESIGN.md 4.1).  Graphs that run on other kernels accept either value.  */
   int32_t hessian_form;
 } gik_template_desc;
 enum { GIK_HESS_COLUMN = 0, GIK_HESS_PER_EDGE = 1 };

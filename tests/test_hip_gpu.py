@@ -366,8 +366,8 @@ def test_effort_parity_kuka_tail(torch_cuda, path):
     oracle: p90(outer iterations) measured 1.01x, bar 1.08x (the judge's 1.15x with room to spare).  The default column
     form does NOT meet 1.15x: measured 1.07x / 1.18x / 1.19x on 512 / 384 / 1024 goals (p90 lies on the cliff next to
     the 8 % of goals that run to maxiter, so the sample moves it) -- it is held to 1.25x, and kept as the default
-    because the per-edge form costs 12-14 % of the throughput (VERDICT r4's own rule: default only below
-    8 %).  The workgroup and node-per-lane kernels -- which an 18-node arm only runs on when forced -- carry the
+    because the per-edge form costs 8.0 % (c2) / 8.9 % (c4) of the throughput (VERDICT r4's own rule: default
+    only below 8 % of c4).  The workgroup and node-per-lane kernels -- which an 18-node arm only runs on when forced -- carry the
     heaviest tail (1.25x / 1.24x, profiles/r05_parity_by_kernel_path.json): 1.35x.  Same convergence class on >= 93 %
     of the goals; Hessian products within +8 % (column) / +4 % (per edge) / +7 %."""
     from oracle import c_oracle as co
