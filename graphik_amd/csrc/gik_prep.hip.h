@@ -1257,7 +1257,8 @@ __device__ inline double wrap_pi(double e) {
   return m - 3.141592653589793;
 }
 
-__global__ void recover_kernel(RecoverArgs a) {
+// (launched with 64 threads per block; without the bound the compiler budgets for 1024 and 128 VGPRs: 252 B of scratch)
+__global__ void __launch_bounds__(64) recover_kernel(RecoverArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
   const PipeConst &pc = a.pc;
