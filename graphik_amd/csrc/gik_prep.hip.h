@@ -276,7 +276,11 @@ struct PrepArgs {
   int no_compress;       // workgroup kernel: 1 = full N x N Jacobi even for rank-deficient Gram matrices (tests, A/B)
 };
 
-__global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
+__global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a)
+#ifndef GIK_DEFINE_PLAIN_KERNELS
+    ;      // (defined in gik_k_prep.hip)
+#else
+{
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const PipeConst &pc = a.pc;
   const int N = pc.N, K = pc.K, NN = N * N, lane = threadIdx.x;
@@ -490,6 +494,7 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a) {
     __builtin_amdgcn_wave_barrier();
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // prep_block_kernel: the same pre-processing for graphs beyond one wavefront's LDS (N <= 128, up to
@@ -1258,7 +1263,11 @@ __device__ inline double wrap_pi(double e) {
 }
 
 // (launched with 64 threads per block; without the bound the compiler budgets for 1024 and 128 VGPRs: 252 B of scratch)
-__global__ void __launch_bounds__(64) recover_kernel(RecoverArgs a) {
+__global__ void __launch_bounds__(64) recover_kernel(RecoverArgs a)
+#ifndef GIK_DEFINE_PLAIN_KERNELS
+    ;      // (defined in gik_k_prep.hip)
+#else
+{
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
   const PipeConst &pc = a.pc;
@@ -1416,6 +1425,7 @@ __global__ void __launch_bounds__(64) recover_kernel(RecoverArgs a) {
     a.rot_err[b] = fabs(wrap_pi(gphi - phi));
   }
 }
+#endif
 
 
 // ---------------------------------------------------------------------------------------------
@@ -1448,7 +1458,11 @@ __device__ inline void anchor_world(const AnchGlueArgs &a, const double *Tg, int
   }
 }
 
-__global__ void anch_init_kernel(AnchGlueArgs a) {
+__global__ void anch_init_kernel(AnchGlueArgs a)
+#ifndef GIK_DEFINE_PLAIN_KERNELS
+    ;      // (defined in gik_k_prep.hip)
+#else
+{
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
   const double *Tg = a.T_goal + (size_t)b * 16;
@@ -1512,8 +1526,13 @@ __global__ void anch_init_kernel(AnchGlueArgs a) {
     for (int c = 0; c < 3; ++c) a.anchor_goal[((size_t)b * a.n_goal + (r - a.goal_row0)) * 3 + c] = w[c];
   }
 }
+#endif
 
-__global__ void anch_gather_kernel(AnchGlueArgs a) {
+__global__ void anch_gather_kernel(AnchGlueArgs a)
+#ifndef GIK_DEFINE_PLAIN_KERNELS
+    ;      // (defined in gik_k_prep.hip)
+#else
+{
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
   const double *Tg = a.T_goal + (size_t)b * 16;
@@ -1527,5 +1546,6 @@ __global__ void anch_gather_kernel(AnchGlueArgs a) {
     for (int c = 0; c < 3; ++c) Y[a.anchor_full[r] * 3 + c] = w[c];
   }
 }
+#endif
 
 }  // namespace gik

@@ -79,7 +79,7 @@ typedef struct {
   int32_t slice_outer_its;   /* time slice in outer iterations: a problem yields its slot to whatever
                                 waits after that many; -1 = default (256; node-per-lane kernel 192; on the
                                 wavefront kernel only for batches beyond the resident waves), 0 = off */
-  int32_t debug_flags;       /* developer flags (gik_solve.hip: SolveArgs::dbg); 16 = rerun tCG
+  int32_t debug_flags;       /* developer flags (gik_kernels.hip.h: SolveArgs::dbg); 16 = rerun tCG
                                 after a rejected step instead of resuming from the checkpoint;
                                 workgroup path: 64 = closed form for rigid cliques from 4 nodes
                                 up (default: 16 nodes); 128 / 256 = older spellings of

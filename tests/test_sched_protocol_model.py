@@ -1,5 +1,5 @@
 """Exhaustive interleaving check of the wavefront kernel's yield-queue protocol (round-robin time
-slicing; graphik_amd/csrc/gik_solve.hip: rtr_wave_kernel<.., MIG> and mig_wait, SolveArgs::y_*).
+slicing; graphik_amd/csrc/gik_kernels.hip.h: rtr_wave_kernel<.., MIG> and mig_wait, SolveArgs::y_*).
 
 The device code takes yield-queue entries by fetch-add tickets (no compare-and-swap), which is only
 safe if a ticket's entry is guaranteed to exist.  This file restates the protocol as a state machine

@@ -1,6 +1,6 @@
 // tools/exp/gik_quad3.hip.h -- four 3-D IK problems per wavefront (gfx950 / CDNA4): an EXPERIMENT of round 4,
 // measured slower than rtr_wave_kernel and therefore not part of the library (docs/NOTEBOOK.md 9.9 has the numbers
-// and how it was wired into gik_solve.hip; tools/attic/dev_quad3_check.py is the check that was run).
+// and how it was wired into gik_kernels.hip.h; tools/attic/dev_quad3_check.py is the check that was run).
 //
 // The throughput regime of the wavefront kernel (rtr_wave_kernel, one unknown per lane) is bound by
 // instruction issue: 162 VALU instructions per Hessian product, two waves per SIMD at 82 % of the
@@ -252,7 +252,7 @@ struct Quad3Ctx {
   }
 };
 
-// The kernel body (instantiated in gik_solve.hip: SolveArgs lives there).
+// The kernel body (instantiated in gik_kernels.hip.h: SolveArgs lives there).
 template <int DEG, int NS, typename Args>
 __device__ inline void rtr_quad3_body(const Args &a, double *smem) {
   using Ctx = Quad3Ctx<DEG, NS>;
