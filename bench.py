@@ -59,6 +59,16 @@ def algorithmic_flops(N, k, T, n_inner, n_outer, n_accept):
     return n_inner * F_hv + n_outer * F_cost + n_accept * F_acc
 
 
+def library_digest():
+    """Digest of the sources the loaded libgraphik_amd.so was built from (graphik_amd/build.py writes it next to the
+    library): the key that ties a profile under profiles/ to a binary."""
+    try:
+        from graphik_amd import _ffi
+        return open(_ffi.LIB_PATH + ".digest").read().strip()
+    except Exception:
+        return None
+
+
 def prepare_flops(N, K):
     """F_init ~ 2 * 9 N^3 + 9 K^3 (two N x N and one K x K Jacobi-class eigendecomposition) per
     goal, plus bound smoothing as the kernels run it: Floyd-Warshall on UPPER (N^3 add + min = 2 N^3) and
@@ -92,10 +102,11 @@ def parse_args(argv=None):
     ap.add_argument("--serving-streams", type=int, default=16,
                     help="extra, separately labelled measurement after the timed region: the same "
                          "batches issued round-robin on this many HIP streams (0 = skip)")
-    ap.add_argument("--hessian-form", choices=["column", "per_edge"], default="column",
+    ap.add_argument("--hessian-form", choices=["auto", "column", "per_edge"], default="auto",
                     help="3-D arms on the wavefront kernel: how lhess is rendered (gik_template_desc.hessian_form); "
-                         "per_edge = s = y.w once per edge as costs.py:186-203 writes it (tighter parity, slower product); "
-                         "the BASELINE line is the default, column")
+                         "auto (the library's default, the BASELINE line) = per_edge: s = y.w once per edge as "
+                         "costs.py:186-203 writes it; column = the cached-rows form that was the default until round 5 "
+                         "(+5-8 % Hessian products against the reference's arithmetic)")
     ap.add_argument("--intended", action="store_true",
                     help="ur10_table only: the opt-in fixed-anchor formulation with the robot<->obstacle "
                          "hinges the reference means to create (SURVEY 8(f)3); NOT the reference's observable "
@@ -189,8 +200,9 @@ def cpu_baseline(prob, T_goal, Y0_h, B, args):
         pass
     cores = max(1, min(usable, int(quota)) if quota else usable)
 
-    def run(ns, nthreads):
-        D, _, _ = prob.assemble(T_goal[:ns])
+    def run(ns, nthreads, D=None):
+        if D is None:
+            D, _, _ = prob.assemble(T_goal[:ns])
         t0 = time.perf_counter()
         o = co.rtr_solve_batch(Y0_h[:ns], D, prob.omega, prob.psi_L, prob.psi_U, prob.psi_L is not None,
                                nthreads=nthreads, fast=True)
@@ -202,13 +214,18 @@ def cpu_baseline(prob, T_goal, Y0_h, B, args):
     n1 = min(B, 2 if big else (256 if planar else 24))
     t1, hv1 = run(n1, 1)
     # a bounded sample (>= 256 problems per config, the table scene >= 16): ~5-20 s of CPU work
-    ns = args.cpu_sample or min(B, max(16, 2 * cores) if big else (4096 if planar else max(256, 64 * cores)))
-    tc, hvc = run(ns, cores)
+    ns = args.cpu_sample or min(B, max(16, 2 * cores) if big else (65536 if planar else max(256, 64 * cores)))
+    Ds, _, _ = prob.assemble(T_goal[:ns])
+    tc, hvc = run(ns, cores, Ds)
+    reps = 1
+    if tc < 0.3:      # planar goals: ~2 us each -- repeat the sample until the clock has something to measure
+        reps = int(np.ceil(0.3 / max(tc, 1e-4))) + 1
+        tc = sum(run(ns, cores, Ds)[0] for _ in range(reps)) / reps
     return {
         "value": ns / tc, "unit": "solves/s", "cores": cores, "kind": "port",
         "sample": f"first {ns} goals of rank 0's batch ({ns / cores:.1f} per thread), "
                   f"oracle/gik_oracle.c (-O3 AVX2+FMA), OpenMP dynamic schedule over problems, "
-                  f"{tc:.1f} s wall",
+                  f"{tc * reps:.2f} s wall" + (f" ({reps} repeats of the sample)" if reps > 1 else ""),
         "hv_total": hvc, "hv_per_s_per_thread": hvc / tc / cores,
         "single_thread": {"value": n1 / t1, "unit": "solves/s", "sample": f"first {n1} goals, {t1:.1f} s",
                           "hv_per_s": hv1 / t1},
@@ -286,7 +303,10 @@ class Bench:
         for _ in range(steps):
             st = dry_solve(T_goal, robot.n)
         gd.barrier()
-        dt = gd.max_over_ranks(time.perf_counter() - t0, self.dev)
+        dt_local = time.perf_counter() - t0
+        dt = gd.max_over_ranks(dt_local, self.dev)
+        per_rank = gd.gather_vectors([dt_local / steps * 1e3, float(st["iterations"].max()) if B else 0.0,
+                                      float(np.mean(st["stop"] == 1)) if B else 0.0, float(B)], self.dev)
         # the library's result table (q + statistics per problem) and its ONE gather
         allstats = gd.gather_rows(gd.pack_results(st), total, dst=0)
         if self.rank != 0:
@@ -298,12 +318,13 @@ class Bench:
             "ms_per_step": dt / steps * 1e3, "scaling": scaling,
             "config": {"workload": f"{robot_name}, {total} goals over {self.world} rank(s)",
                        "config": cfg, "robot": robot_name, "goals_total": total},
+            "per_rank": [dict(zip(("ms", "max_outer", "frac_maxiter", "goals"), v)) for v in per_rank],
             "rows": int(a.shape[0]), "row_bytes": int(a.shape[1]) * 8, "checksum": float(a.sum()),
             "rows_sha": __import__("hashlib").sha256(np.ascontiguousarray(a).tobytes()).hexdigest(),
         }
 
     def measure(self, cfg, robot_name, total, scaling, steps, warmup, serving_streams=0,
-                cpu=False, n_streams=1, intended=False, seed=None, use_limits=True):
+                cpu=False, n_streams=1, intended=False, seed=None, use_limits=True, hessian_form=None):
         if self.dry:
             return self.measure_dry(cfg, robot_name, total, scaling, steps, warmup)
         args, torch, gd, dev, rank, world = self.args, self.torch, self.gd, self.dev, self.rank, self.world
@@ -320,8 +341,9 @@ class Bench:
             N, k = len(anch.free), 3
             T = anch.template.T + len(anch.pin)              # terms the Hessian product sees
         else:
+            form = hessian_form or self.args.hessian_form
             prob = BatchProblem(graph, use_limits=use_limits, device=dev,
-                                params=({"hessian_form": 1} if self.args.hessian_form == "per_edge" else None))
+                                params=(None if form == "auto" else {"hessian_form": form}))
             N, k, T = graph.number_of_nodes(), graph.dim, prob.template.T
         tpl = prob.template
         on_device = prob.device_pipeline
@@ -383,6 +405,11 @@ class Bench:
         gd.barrier()
         dt_local = time.perf_counter() - t0
         dt = gd.max_over_ranks(dt_local, dev)
+        # what every rank saw: a shard is as long as ITS longest problem, so the first hardware scaling run
+        # can be read against DESIGN 5's straggler model rank by rank (a few doubles per rank, outside the timed region)
+        its_l = res["iterations"].double()
+        per_rank = gd.gather_vectors([dt_local / steps * 1e3, float(its_l.max()) if B else 0.0,
+                                      float((res["stop"] == 1).double().mean()) if B else 0.0, float(B)], dev)
         if anch is not None:
             # The events around the anchored solve kernel live inside the C call and reading them waits
             # for it, so the per-step kernel time is taken in a pass of its own AFTER the timed region
@@ -419,7 +446,7 @@ class Bench:
             torch.cuda.synchronize(dev)
             gd.barrier()
             dts = gd.max_over_ranks(time.perf_counter() - ts, dev)
-            serving = {"value": total * nb / dts, "unit": "solves/s", "batches_in_flight": S,
+            serving = {"value": total * nb / dts, "unit": "solves/s", "batches_in_flight": S, "seconds": dts,
                        "batches": nb, "ms_per_batch": dts / nb * 1e3,
                        "note": "same workload and kernels as `value`; S batches in flight on separate HIP "
                                "streams (a serving configuration: independent requests overlap, the "
@@ -469,8 +496,8 @@ class Bench:
             kernel_name = f"rtr_quad_kernel<{info['max_terms_per_node']}> (four planar problems per wavefront)"
         else:
             kernel_name = f"rtr_wave_kernel<{k},{info['max_terms_per_node'] if info else prob.template.maxdeg}>"
-            if info and info.get("hessian_form"):
-                kernel_name += " (per-edge product form)"
+            if info and k == 3:
+                kernel_name += " (per-edge product form)" if info.get("hessian_form") else " (column-form product)"
         flops_exec = executed_flops(N, k, T, info if anch is None else None, lowrank_local,
                                     exec_local, outer_local, acc_local)
         executed_tf = flops_exec / (kernel_ms * 1e-3) / 1e12
@@ -529,7 +556,10 @@ class Bench:
                              "bytes_per_launch": hbm_bytes},
         }
         out["gather"] = gather
+        out["per_rank"] = [dict(zip(("ms", "max_outer", "frac_maxiter", "goals"), v)) for v in per_rank]
         if serving is not None:
+            # the same flops per batch as the timed region's, S batches in flight: what the chip does on this config
+            serving["frac"] = flops * serving["batches"] / serving.pop("seconds") / 1e12 / FP64_PEAK_TFLOPS
             out["serving"] = serving
         # every kernel of the step (HIP events on the launch stream), which of them dominates, and -- when it
         # is the prepare kernel (planar-10: c5) -- its own roofline entry next to the solve kernel's
@@ -558,10 +588,14 @@ class Bench:
             out["kernels"] = {"prepare_ms": None, "solve_ms": kernel_ms, "recover_ms": None, "dominant": out["roofline"]["kernel"]}
         # HBM traffic of the solve kernel from the PMC passes of the SAME workload (tools/profile.sh:
         # rocprofv3 cannot run inside this process), newest round first; null for unprofiled workloads
-        tags = {("lwa4d", 4096): ["r05", "r04", "r03", "r02"], ("ur10_table", 4096): ["r05_c3", "r04_c3"],
-                ("kuka", 65536): ["r05_c4", "r04_c4", "r03_c4"], ("kuka", 8192): ["r05_c4share", "r04_c4share", "r03_c4share"],
-                ("planar10", 65536): ["r05_c5", "r04_c5", "r03_c5", "r02_c5"]}
+        tags = {("lwa4d", 4096): ["r06", "r05", "r04", "r03", "r02"], ("ur10_table", 4096): ["r06_c3", "r05_c3", "r04_c3"],
+                ("kuka", 65536): ["r06_c4", "r05_c4", "r04_c4", "r03_c4"],
+                ("kuka", 8192): ["r06_c4share", "r05_c4share", "r04_c4share", "r03_c4share"],
+                ("planar10", 65536): ["r06_c5", "r05_c5", "r04_c5", "r03_c5", "r02_c5"]}
+        if hessian_form == "column":      # (the column-form comparison lines: their own profiles, if any)
+            tags = {kk: [t + "_column" for t in v] for kk, v in tags.items()}
         out["roofline"]["traffic_measured"] = None
+        lib_digest = library_digest()
         for tag in ([] if intended else tags.get((robot_name, B), [])):
             traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json" if tag == "r02" else f"{tag}_hbm_traffic.json")
             if not os.path.exists(traffic_file):
@@ -575,6 +609,9 @@ class Bench:
                 out["roofline"]["traffic_ratio"] = tj.get("bytes_per_launch") / hbm_bytes if hbm_bytes else None
                 out["roofline"]["traffic_source"] = src
                 out["roofline"]["traffic_measured"] = "profiles (separate rocprofv3 run), not in-process"
+                # counters are a property of the BINARY they were read from: the profile carries the digest of the
+                # library's sources (tools/summarize_prof.py); anything else is an old measurement and says so
+                out["roofline"]["traffic_stale"] = tj.get("source_digest") != lib_digest
                 pj = tj.get("prepare")
                 if pj and "roofline_prepare" in out:
                     rp = out["roofline_prepare"]
@@ -582,6 +619,7 @@ class Bench:
                     rp["traffic_ratio"] = pj.get("bytes_per_launch") / rp["bytes_per_launch"]
                     rp["lds_bank_conflict_ratio"] = pj.get("lds_bank_conflict_ratio")
                     rp["traffic_source"] = src
+                    rp["traffic_stale"] = out["roofline"]["traffic_stale"]
                 break
             except Exception:
                 pass
@@ -657,9 +695,11 @@ def main():
                 ("c5_nolimits", "planar10", 65536, "strong", 5, 1)]      # use_limits=False & True
         if b.world == 1:
             plan.insert(2, ("c4_share_of_8", "kuka", 8192, "strong", 5, 1))
+        # the column-form product beside the default (per-edge) lines of the two configs it concerns
+        plan += [("c2_column", robot_name, total, scaling, 3, 1), ("c4_column", "kuka", 65536, "strong", 3, 1)]
         for name, rb, tot, sc, st, wu in plan:
-            o = b.measure(name[:2], rb, tot, sc, st, wu, cpu=(name != "c4_share_of_8"),
-                          use_limits=(name != "c5_nolimits"))
+            o = b.measure(name[:2], rb, tot, sc, st, wu, cpu=(name != "c4_share_of_8" and not name.endswith("_column")),
+                          use_limits=(name != "c5_nolimits"), hessian_form=("column" if name.endswith("_column") else None))
             if b.rank == 0:
                 extra[name] = brief(o)
         # the headline on seeds 0-3: `value` stays seed 0; a 4096-goal batch is as long as
@@ -688,11 +728,17 @@ def main():
                     "prep_frac": sig(rp.get("frac")), "prep_traffic_x": sig(rp.get("traffic_ratio")),
                     "cpu": sig((o.get("cpu_baseline") or {}).get("value"))}
         summ = {cfg if cfg else "custom": tiny(out)}
+        if out.get("serving"):      # sixteen batches in flight: what the chip does on this config (NOT `value`)
+            summ[cfg if cfg else "custom"].update(serving=float("%.4g" % out["serving"]["value"]),
+                                                  serving_frac=float("%.4g" % out["serving"]["frac"]))
         for name, o in (out.get("configs") or {}).items():
             if o and "value" in o:
                 summ[name] = tiny(o)
         out["summary"] = {"unit": "solves/s; ms per step; roofline fractions of the fp64 vector peak (algorithmic / executed); "
-                                  "traffic_x = HBM bytes per launch (PMC, profiles/) / algorithmic bytes; cpu = oracle solves/s",
+                                  "traffic_x = HBM bytes per launch (PMC, profiles/) / algorithmic bytes; cpu = oracle solves/s; "
+                                  "serving = solves/s with 16 batches in flight; *_column = the same config with "
+                                  "hessian_form = column (the default is the per-edge product form)",
+                          "traffic_stale": bool((out.get("roofline") or {}).get("traffic_stale")),
                           "traffic_measured": "profiles/ (separate rocprofv3 --pmc runs), not in-process", **summ}
         print(json.dumps(out), flush=True)
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GIK_LIB_PATH") or os.path.join(_HERE, "lib", "libgraphik_amd.so")
 
 TERM_EQ, TERM_LOWER, TERM_UPPER = 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class TemplateDesc(C.Structure):
@@ -34,7 +34,7 @@ class TemplateDesc(C.Structure):
 
 
 CLIQUE_AUTO, CLIQUE_OFF, CLIQUE_DENSE = 0, 1, 2
-HESS_COLUMN, HESS_PER_EDGE = 0, 1
+HESS_COLUMN, HESS_PER_EDGE, HESS_AUTO = 0, 1, 2
 
 
 class TemplateInfo(C.Structure):

@@ -57,6 +57,12 @@ static size_t lds_bytes_of(int T) {
 }
 
 template <int K, int D>
+static size_t lds_bytes_strict(int T) {
+  if constexpr (K == 3) return WaveCtxStrict<D>::lds_bytes(T);
+  return 0;
+}
+
+template <int K, int D>
 static size_t lds_bytes_anch(int T) {
   return WaveCtx<K, D, true>::lds_bytes(T);
 }
@@ -73,23 +79,24 @@ struct Variant {
   solve_fn solve_mig;    // theta == 1 with tail spreading (MigCtl), or null
   solve_fn solve_strict, solve_strict_mig;   // hessian_form = GIK_HESS_PER_EDGE (k = 3, theta == 1), or null
   kat_fn kat_strict;
+  lds_fn lds_strict;
 };
 #define GIK_VARIANT(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
-   lds_bytes_of<K, D>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
+   lds_bytes_of<K, D>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
 #define GIK_VARIANT_S(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
    lds_bytes_of<K, D>, nullptr, nullptr, nullptr, nullptr, rtr_wave_kernel<K, D, true, false, false, true>, \
-   rtr_wave_kernel<K, D, true, false, true, true>, kat_wave_kernel<K, D, false, true>}
+   rtr_wave_kernel<K, D, true, false, true, true>, kat_wave_kernel<K, D, false, true>, lds_bytes_strict<K, D>}
 #define GIK_VARIANT_A(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
    lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, nullptr, \
-   nullptr, nullptr, nullptr}
+   nullptr, nullptr, nullptr, nullptr}
 #define GIK_VARIANT_AM(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
    lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, \
    rtr_wave_kernel<K, D, true, false, true>, rtr_wave_kernel<K, D, true, false, false, true>, \
-   rtr_wave_kernel<K, D, true, false, true, true>, kat_wave_kernel<K, D, false, true>}
+   rtr_wave_kernel<K, D, true, false, true, true>, kat_wave_kernel<K, D, false, true>, lds_bytes_strict<K, D>}
 // anchored templates only: the free-free formulation with more than 10 terms at a node runs on the
 // workgroup kernels (the 20-slot wavefront variant needed 796 B of scratch per lane: measured on the
 // two-end-effector tree of tests/golden/tree5.npz, 13 terms, 144 k against 382 k solves/s;
@@ -97,7 +104,7 @@ struct Variant {
 // workgroup kernels on the planar trees -- both stay)
 #define GIK_VARIANT_ANCH_ONLY(K, D) \
   {K, D, nullptr, nullptr, nullptr, nullptr, lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, \
-   kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, nullptr, nullptr, nullptr, nullptr}
+   kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, nullptr, nullptr, nullptr, nullptr, nullptr}
 static const Variant kVariants[] = {GIK_VARIANT_AM(3, 9), GIK_VARIANT_S(3, 10), GIK_VARIANT_ANCH_ONLY(3, 20),
                                     GIK_VARIANT(2, 6), GIK_VARIANT(2, 16), GIK_VARIANT(2, 31)};
 
@@ -135,7 +142,7 @@ struct gik_template {
                             // (a slot marked in_use belongs to its call: blocking work happens outside the lock)
   std::mutex ev_mutex;      // ev_solve0 / ev_solve1 (anchored templates)
   int clique_mode = 0;      // gik_template_desc::clique_closed_form as resolved at creation
-  bool hess_per_edge = false;   // gik_template_desc::hessian_form = GIK_HESS_PER_EDGE on the wavefront kernel (k = 3)
+  bool hess_per_edge = false;   // the wavefront kernel (k = 3) runs the per-edge product form (gik_template_desc::hessian_form)
   // time-slicing workspaces (re-queue ring + paused state), a small pool handed out round-robin;
   // a launch that gets a slot still in use by an earlier launch waits for it on its stream
   struct SliceWs {
@@ -264,7 +271,7 @@ void gik_default_params(gik_template_desc *d) {
   d->cg_orth_value = 10e10;     // :57
   d->cg_beta_type = 3;          // :58  BetaTypes[3] = HagerZhang
   d->clique_closed_form = GIK_CLIQUE_AUTO;
-  d->hessian_form = GIK_HESS_COLUMN;
+  d->hessian_form = GIK_HESS_AUTO;
 }
 
 void gik_default_cg_params(gik_template_desc *d) {
@@ -305,8 +312,8 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   if (d->cg_beta_type < 0 || d->cg_beta_type > 3) return fail("cg_beta_type must be 0..3");
   if (d->clique_closed_form < GIK_CLIQUE_AUTO || d->clique_closed_form > GIK_CLIQUE_DENSE)
     return fail("clique_closed_form must be GIK_CLIQUE_AUTO, _OFF or _DENSE");
-  if (d->hessian_form != GIK_HESS_COLUMN && d->hessian_form != GIK_HESS_PER_EDGE)
-    return fail("hessian_form must be GIK_HESS_COLUMN or GIK_HESS_PER_EDGE");
+  if (d->hessian_form != GIK_HESS_COLUMN && d->hessian_form != GIK_HESS_PER_EDGE && d->hessian_form != GIK_HESS_AUTO)
+    return fail("hessian_form must be GIK_HESS_AUTO, GIK_HESS_COLUMN or GIK_HESS_PER_EDGE");
 
   bool is_block = d->N * d->k > WAVE || d->N > 32 || d->force_block_path != 0;
   // 255 = what the node-per-lane kernel's 8-bit row fields take (four wavefronts per problem beyond 128 nodes);
@@ -692,14 +699,16 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   t->T = T;
   t->maxdeg = is_block ? SL : MD;
   t->variant = var;
-  // the per-edge product form concerns the one-unknown-per-lane kernel only (every other kernel forms s = y . w per
-  // edge anyway); there it exists for k = 3, TrustRegions, theta = 1, free-free graphs
-  if (d->hessian_form == GIK_HESS_PER_EDGE && !is_block && d->k == 3) {
-    if (ad || d->solver != GIK_SOLVER_TRUST_REGIONS || d->theta != 1.0 || !var->solve_strict) {
+  // The product form concerns the one-unknown-per-lane kernel only (every other kernel forms s = y . w per edge
+  // anyway).  There the per-edge form exists for k = 3, TrustRegions, theta = 1, free-free graphs and is what
+  // GIK_HESS_AUTO selects; an explicit GIK_HESS_PER_EDGE without such a kernel is refused.
+  if (!is_block && d->k == 3 && d->hessian_form != GIK_HESS_COLUMN) {
+    const bool have = !ad && d->solver == GIK_SOLVER_TRUST_REGIONS && d->theta == 1.0 && var->solve_strict;
+    if (!have && d->hessian_form == GIK_HESS_PER_EDGE) {
       delete t;
       return fail("hessian_form = GIK_HESS_PER_EDGE: wavefront kernel of 3-D free-free graphs, TrustRegions, theta = 1 only");
     }
-    t->hess_per_edge = true;
+    t->hess_per_edge = have;
   }
   t->p.mingradnorm = d->mingradnorm;
   t->p.theta = d->theta;
@@ -746,7 +755,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   t->has_pipe = false;
   t->smem_bytes = is_block ? (d->k == 3 ? BlockCtx<3>::lds_bytes(Tc, SL, (int)clq_pair_term.size(), n_clq)
                                         : BlockCtx<2>::lds_bytes(Tc, SL))
-                           : (ad ? var->lds_anch(T) : var->lds(T));
+                           : (ad ? var->lds_anch(T) : (t->hess_per_edge ? var->lds_strict(T) : var->lds(T)));
   if (is_block && t->smem_bytes > 160 * 1024) {
     delete t;
     return fail("graph too large for the LDS-resident block path");
@@ -755,7 +764,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   const void *solve_kernel =
       is_block ? (cg ? (d->k == 3 ? (const void *)rcg_block_kernel<3> : (const void *)rcg_block_kernel<2>)
                      : (d->k == 3 ? (const void *)rtr_block_kernel<3> : (const void *)rtr_block_kernel<2>))
-               : (const void *)(ad ? var->solve_anch : (cg ? var->solve_cg : var->solve));
+               : (const void *)(ad ? var->solve_anch : (cg ? var->solve_cg : (t->hess_per_edge ? var->solve_strict : var->solve)));
   if (is_block && t->smem_bytes > 48 * 1024) {
     // more than the default dynamic-LDS allowance: opt in for exactly what this template needs
     const void *fns[2] = {solve_kernel, d->k == 3 ? (const void *)kat_block_kernel<3>
@@ -1445,6 +1454,10 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   // LWA4D goals a third of the launches drew such a pair (128 instead of 116 ms).
   int wpc = t->is_npt ? t->npt_waves_per_cu : t->waves_per_cu;
   if (!t->is_block && t->K == 3 && wpc > 4 && (long long)B <= 6LL * 4 * t->n_cu) wpc = 4;
+  // THREE waves per SIMD (the per-edge form: 153 VGPRs, 8.3 KB of LDS) only for queues of 128 problems per CU and more:
+  // measured round 6 on KUKA, 65536 goals 130.5 k -> 134.2 k solves/s (+2.9 %), but 8192 goals 55.4 k -> 51.5 k (-7 %) --
+  // a mid-size batch is its stragglers, and a straggler with two co-resident waves runs slower than with one
+  if (!t->is_block && t->K == 3 && wpc > 8 && (long long)B < 128LL * t->n_cu) wpc = 8;
   if (t->wpc_override > 0) wpc = t->wpc_override;
   const int grid = std::min(B, t->n_cu * wpc);
   // Time slicing (workgroup-per-problem kernel): only when there are more problems than resident
@@ -1587,7 +1600,7 @@ int gik_template_get_info(const gik_template *t, gik_template_info *info) {
   info->n_cu = t->n_cu;
   info->lds_bytes = (int32_t)t->smem_bytes;
   info->clique_closed_form = t->clique_mode;
-  info->hessian_form = t->hess_per_edge ? GIK_HESS_PER_EDGE : GIK_HESS_COLUMN;
+  info->hessian_form = (t->hess_per_edge || t->is_block) ? GIK_HESS_PER_EDGE : GIK_HESS_COLUMN;
   info->anchored = t->anchored ? 1 : 0;
   info->has_pipeline = t->has_pipe ? 1 : 0;
   info->prepare_is_block = t->prep_block ? 1 : 0;

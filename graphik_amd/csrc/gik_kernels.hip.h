@@ -33,7 +33,11 @@
 #include "gik_rtr.hip.h"
 #include "gik_rtrv.hip.h"
 #include "gik_wave.hip.h"
+#ifdef GIK_STRICT_HEADER      // developer experiments (tools/exp/strict_bisect.sh): another rendering of WaveCtxStrict
+#include GIK_STRICT_HEADER
+#else
 #include "gik_wave_strict.hip.h"
+#endif
 #include "graphik_amd.h"
 
 namespace gik {
@@ -211,9 +215,21 @@ __device__ inline void dev_log(double *buf, int type, int b) {
 // padding slots read the never-written dump row, which must hold finite zeros).
 template <typename Ctx>
 __device__ inline void stage_lds(double *tiles, uint32_t *meta, const uint32_t *g_meta, int lane,
-                                 int maxdeg, int ktiles) {
-  for (int t = lane; t < ktiles * Ctx::TILE; t += WAVE) tiles[t] = 0.0;
-  for (int s = 0; s < maxdeg; ++s) meta[s * WAVE + lane] = g_meta[s * WAVE + lane];
+                                 int maxdeg, int N) {
+  for (int t = lane; t < Ctx::NTILE * Ctx::TILE; t += WAVE) tiles[t] = 0.0;
+  if constexpr (Ctx::SLIM_LAYOUT) {
+    // slim layout (per-edge context): table row k of a lane is node slot comp + 3 k, the slots the lane OWNS; beyond the
+    // compiled slot count: the padding word of the host's table (own row -- idle lanes: the dump row --, kind none)
+    const bool active = lane < N * 3;
+    const int comp = active ? lane % 3 : 0;
+    const uint32_t pad = meta_pack(active ? lane / 3 : TILE_ROWS - 1, 0, 0, 0);
+    for (int k = 0; k < Ctx::NSL; ++k) {
+      const int s = comp + 3 * k;
+      meta[k * WAVE + lane] = s < maxdeg ? g_meta[s * WAVE + lane] : pad;
+    }
+  } else {
+    for (int s = 0; s < maxdeg; ++s) meta[s * WAVE + lane] = g_meta[s * WAVE + lane];
+  }
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -235,9 +251,9 @@ __global__ void __launch_bounds__(WAVE, ANCH ? 1 : 2) rtr_wave_kernel(SolveArgs 
   const int lane = threadIdx.x;
   const int NK = a.N * K;
   double *sh_tiles = smem;
-  double *sh_tgt = smem + K * Ctx::TILE;
+  double *sh_tgt = smem + Ctx::NTILE * Ctx::TILE;
   uint32_t *sh_meta = reinterpret_cast<uint32_t *>(sh_tgt + ((a.T + 1) & ~1));
-  stage_lds<Ctx>(sh_tiles, sh_meta, a.slot_meta, lane, MAXDEG, K);
+  stage_lds<Ctx>(sh_tiles, sh_meta, a.slot_meta, lane, MAXDEG, a.N);
 
   Ctx cx;
   cx.init(lane, a.N, sh_tiles, sh_tgt, sh_meta);
@@ -439,9 +455,9 @@ __global__ void __launch_bounds__(WAVE, 2) rcg_wave_kernel(SolveArgs a) {
   const int lane = threadIdx.x;
   const int NK = a.N * K;
   double *sh_tiles = smem;
-  double *sh_tgt = smem + K * Ctx::TILE;
+  double *sh_tgt = smem + Ctx::NTILE * Ctx::TILE;
   uint32_t *sh_meta = reinterpret_cast<uint32_t *>(sh_tgt + ((a.T + 1) & ~1));
-  stage_lds<Ctx>(sh_tiles, sh_meta, a.slot_meta, lane, MAXDEG, K);
+  stage_lds<Ctx>(sh_tiles, sh_meta, a.slot_meta, lane, MAXDEG, a.N);
   Ctx cx;
   cx.init(lane, a.N, sh_tiles, sh_tgt, sh_meta);
   int pass = 0;
@@ -507,9 +523,9 @@ __global__ void __launch_bounds__(WAVE) kat_wave_kernel(KatArgs a) {
   const int b = blockIdx.x;
   const int NK = a.N * K;
   double *sh_tiles = smem;
-  double *sh_tgt = smem + K * Ctx::TILE;
+  double *sh_tgt = smem + Ctx::NTILE * Ctx::TILE;
   uint32_t *sh_meta = reinterpret_cast<uint32_t *>(sh_tgt + ((a.T + 1) & ~1));
-  stage_lds<Ctx>(sh_tiles, sh_meta, a.slot_meta, lane, MAXDEG, K);
+  stage_lds<Ctx>(sh_tiles, sh_meta, a.slot_meta, lane, MAXDEG, a.N);
   for (int t = lane; t < a.T; t += WAVE)
     sh_tgt[t] = a.targets ? a.targets[ANCH ? (size_t)t : (size_t)b * a.T + t] : 0.0;
   __builtin_amdgcn_wave_barrier();
@@ -1136,9 +1152,9 @@ __global__ void __launch_bounds__(WAVE) parts_kernel(const uint32_t *slot_meta, 
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   double *sh_tiles = smem;
-  double *sh_tgt = smem + K * Ctx::TILE;
+  double *sh_tgt = smem + Ctx::NTILE * Ctx::TILE;
   uint32_t *sh_meta = reinterpret_cast<uint32_t *>(sh_tgt + ((T + 1) & ~1));
-  stage_lds<Ctx>(sh_tiles, sh_meta, slot_meta, lane, MAXDEG, K);
+  stage_lds<Ctx>(sh_tiles, sh_meta, slot_meta, lane, MAXDEG, N);
   for (int t = lane; t < T; t += WAVE) sh_tgt[t] = 1.0 + 0.01 * t;
   Ctx cx;
   cx.init(lane, N, sh_tiles, sh_tgt, sh_meta);

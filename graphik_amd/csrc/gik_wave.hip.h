@@ -327,11 +327,18 @@ constexpr int ANCH_PMAX = 8;
 constexpr int ANCH_MAXA = 16;   // rows of the pinned-anchor table
 constexpr int ANCH_MAXOBS = 128; // obstacles (staged in LDS: 32 B each)
 
-template <int K, int MAXDEG, bool ANCH = false>
+// SLIM: the layout of the per-edge product form (WaveCtxStrict, gik_wave_strict.hip.h): only the natural-order tile,
+// and slot metadata / slot records of the slots a lane OWNS (node slots comp, comp + 3, ...) -- 8.3 instead of 18.9 KB
+// of LDS per wavefront on a 7-DOF arm, which is what lets three wavefronts share a SIMD (153 VGPRs).
+template <int K, int MAXDEG, bool ANCH = false, bool SLIM = false>
 struct WaveCtx {
+  static_assert(!SLIM || (K == 3 && !ANCH), "the slim layout belongs to the 3-D per-edge context");
   static constexpr int RS = (K == 3) ? 6 : 2;  // LDS row stride in doubles (48 B / 16 B)
   static constexpr int NC = (K == 3) ? 3 : 1;  // independent entries of the skew matrix
   static constexpr int TILE = TILE_ROWS * RS;  // doubles per rotated tile
+  static constexpr bool SLIM_LAYOUT = SLIM;
+  static constexpr int NTILE = SLIM ? 1 : K;   // tiles kept in LDS
+  static constexpr int NSL = SLIM ? (MAXDEG + 2) / 3 : MAXDEG;   // slots per lane in the LDS tables
   // Per (slot, lane) record for cost()/commit(): the residual target of the slot's term and the
   // clamp bounds that encode its kind -- EQ (-inf, +inf), LOWER (0, +inf), UPPER (-inf, 0),
   // padding (0, 0) -- so that with u = target - d the residual is clamp(u, lo, hi) for every kind
@@ -345,8 +352,8 @@ struct WaveCtx {
   static constexpr bool HAS_CK = (K == 3);
   static constexpr bool AGE_PRIORITY = true;   // waves of different problems share a SIMD (rtr_solve_one)
   __host__ __device__ static constexpr size_t lds_bytes(int T) {
-    return sizeof(double) * ((size_t)K * TILE + (size_t)((T + 1) & ~1)) +
-           sizeof(uint32_t) * (size_t)MAXDEG * WAVE + sizeof(SlotRec) * (size_t)MAXDEG * WAVE +
+    return sizeof(double) * ((size_t)NTILE * TILE + (size_t)((T + 1) & ~1)) +
+           sizeof(uint32_t) * (size_t)NSL * WAVE + sizeof(SlotRec) * (size_t)NSL * WAVE +
            (HAS_CK ? sizeof(double) * 4 * WAVE : 0) +
            (ANCH ? sizeof(double) * 4 * (ANCH_MAXA + ANCH_MAXOBS) + 16 * (size_t)ANCH_PMAX * WAVE +
                        48 * (size_t)WAVE : 0);
@@ -464,7 +471,7 @@ struct WaveCtx {
     y[K - 1] = comp == 0 ? yn[2] : (comp == 1 ? yn[0] : yn[1]);
   }
   __device__ static inline SlotRec *rec_base(uint32_t *meta) {
-    return reinterpret_cast<SlotRec *>(meta + MAXDEG * WAVE);
+    return reinterpret_cast<SlotRec *>(meta + NSL * WAVE);
   }
   __device__ inline void ck_put(int i, double v) { sh_ck[i * WAVE + lane] = v; }
   __device__ inline double ck_get(int i) const { return sh_ck[i * WAVE + lane]; }
@@ -512,7 +519,7 @@ struct WaveCtx {
   __device__ inline void put(double v) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int t = 0; t < K; ++t) sh_tile[waddr[t]] = v;
+    for (int t = 0; t < NTILE; ++t) sh_tile[waddr[t]] = v;
     __builtin_amdgcn_wave_barrier();
   }
 
@@ -527,7 +534,7 @@ struct WaveCtx {
   __device__ inline void load_slot_records() {
     const float inf = __builtin_inff();
 #pragma unroll 1
-    for (int s = 0; s < MAXDEG; ++s) {   // once per problem: rolled, to keep register pressure down
+    for (int s = 0; s < NSL; ++s) {   // once per problem: rolled, to keep register pressure down
       const uint32_t m = sh_meta[s * WAVE + lane];
       const int kind = meta_kind(m);
       SlotRec r;
@@ -543,7 +550,7 @@ struct WaveCtx {
                               uint32_t *meta) {
     lane = lane_;
     sh_rec = rec_base(meta);
-    sh_ck = reinterpret_cast<double *>(sh_rec + MAXDEG * WAVE);
+    sh_ck = reinterpret_cast<double *>(sh_rec + NSL * WAVE);
     active = lane < N * K;
     node = active ? lane / K : (TILE_ROWS - 1);
     comp = active ? lane - node * K : 0;
@@ -558,11 +565,13 @@ struct WaveCtx {
     own_off = comp * TILE + node * RS;
     tile_delta = comp * TILE - comp;
     nat_off = node * RS;
+    if constexpr (!SLIM) {
 #pragma unroll
-    for (int s = 0; s < MAXDEG; ++s) {
-      coloff[s] = meta_j(sh_meta[s * WAVE + lane]) * RS + comp;
+      for (int s = 0; s < MAXDEG; ++s) {
+        coloff[s] = meta_j(sh_meta[s * WAVE + lane]) * RS + comp;
 #pragma unroll
-      for (int q = 0; q < K; ++q) bq[s][q] = 0.0;
+        for (int q = 0; q < K; ++q) bq[s][q] = 0.0;
+      }
     }
   }
 

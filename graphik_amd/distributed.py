@@ -43,6 +43,35 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_HAS_GATHER = {"nccl": True, "gloo": True}      # (RCCL and gloo implement gather: no probe, no extra collective)
+
+
+def backend_has_gather():
+    """Whether the process group's backend implements `gather` -- known for RCCL and gloo; for any other backend decided
+    ONCE, by the same probe on every rank (a one-element gather at the first use, where all ranks are in step), never from the text of an
+    exception raised in the middle of a job: a timeout or an asynchronous RCCL error mentions 'gather' too, and a rank
+    that answers it by entering a different collective hangs the others."""
+    be = dist.get_backend()
+    if be not in _HAS_GATHER:
+        rank, world = dist.get_rank(), dist.get_world_size()
+        dev = torch.device("cuda", torch.cuda.current_device()) if be == "nccl" else torch.device("cpu")
+        probe = torch.zeros(1, dtype=torch.float64, device=dev)
+        try:
+            dist.gather(probe, [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
+            ok = 1.0
+        except NotImplementedError:
+            ok = 0.0
+        except RuntimeError as e:
+            if "does not support gather" not in str(e) and "not implemented" not in str(e).lower():
+                raise
+            ok = 0.0
+        # every rank must come to the same answer (a refusal is raised before any communication, on all ranks alike)
+        flag = torch.tensor([ok], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        _HAS_GATHER[be] = bool(flag.item() > 0.5)
+    return _HAS_GATHER[be]
+
+
 # what the last gather_rows() call of this process did: {"collective", "sent_bytes", "recv_bytes"} --
 # a rank other than `dst` must receive nothing (SURVEY 8(e): ONE gather; tests assert recv_bytes == 0)
 LAST_GATHER = {}
@@ -62,13 +91,10 @@ def gather_rows(local, total, dst=0):
     pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    collective = "gather"
-    try:
-        dist.gather(pad, bufs, dst=dst)
-    except (RuntimeError, NotImplementedError) as e:          # a backend build without gather
-        if "gather" not in str(e).lower() and "not supported" not in str(e).lower():
-            raise
-        collective = "all_gather"
+    collective = "gather" if backend_has_gather() else "all_gather"
+    if collective == "gather":
+        dist.gather(pad, bufs, dst=dst)          # (an error here is an error: no silent change of collective)
+    else:
         bufs = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(bufs, pad)
     row_bytes = pad.element_size() * int(np.prod(pad.shape))
@@ -176,6 +202,17 @@ def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_vectors(vec, device):
+    """A few doubles from every rank on every rank ([world][len(vec)] as lists): bookkeeping outside any timed region
+    (bench.py's per-rank record), not part of the data path."""
+    if not dist.is_initialized():
+        return [[float(v) for v in vec]]
+    t = torch.tensor([float(v) for v in vec], dtype=torch.float64, device=device)
+    bufs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, t)
+    return [[float(v) for v in b.cpu()] for b in bufs]
 
 
 def sum_over_ranks(value, device):

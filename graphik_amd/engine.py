@@ -112,7 +112,7 @@ class Template:
             if key == "clique_closed_form" and isinstance(val, str):
                 val = {"auto": _ffi.CLIQUE_AUTO, "off": _ffi.CLIQUE_OFF, "dense": _ffi.CLIQUE_DENSE}[val]
             if key == "hessian_form" and isinstance(val, str):
-                val = {"column": _ffi.HESS_COLUMN, "per_edge": _ffi.HESS_PER_EDGE}[val]
+                val = {"column": _ffi.HESS_COLUMN, "per_edge": _ffi.HESS_PER_EDGE, "auto": _ffi.HESS_AUTO}[val]
             setattr(d, key, int(val) if key in ("maxiter", "cg_beta_type", "clique_closed_form", "hessian_form") else val)
         self.params = {f: getattr(d, f) for f in ("mingradnorm", "maxiter", "maxinner", "mininner",
                                                    "theta", "kappa", "rho_prime",

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GIK_ABI_VERSION 5
+#define GIK_ABI_VERSION 6
 
 /* Residual-term kinds: one "term" per (index pair, kind) exactly as the loops of
  * costs.py:80-207 visit them: equality (omega != 0), lower hinge (psi_L != 0), upper hinge
@@ -107,17 +107,28 @@ typedef struct {
    * accept / reject threshold can differ from a run with GIK_CLIQUE_OFF (which sums the terms in
    * the reference's order).  gik_stats.flags bit 0 and gik_template_get_info report what ran.   */
   int32_t clique_closed_form; /* GIK_CLIQUE_AUTO (default) | GIK_CLIQUE_OFF | GIK_CLIQUE_DENSE     */
-  /* One-unknown-per-lane wavefront kernel, k = 3 (graphs of N * k <= 64 unknowns: the arms), TrustRegions, theta = 1:
-   * how lhess (costs.py:175-207) is rendered.  GIK_HESS_COLUMN (default): rows of the 3 x 3 blocks 2 a y y^T + c I,
-   * cached per accepted point, times the neighbour's entries -- the cheapest form for that layout, but the scalar
-   * s = y . (W_i - W_j) of costs.py:186-203 is never formed, and truncated CG then needs ~7 % more Hessian products
-   * than the reference's arithmetic from the same start points (7-DOF arms end 8e-3 rad from the reference in the
-   * median instead of 2.5e-3; both inside the band the reference's own two code paths span).  GIK_HESS_PER_EDGE:
-   * s once per edge, t = 2 s a y + c w as written -- the form every other kernel of the library uses -- at ~14 % more
-   * time per product, 8-9 % of the throughput (measured: DESIGN.md 4.1).  Graphs that run on other kernels accept either value.  */
+  /* One-unknown-per-lane wavefront kernel, k = 3 (graphs of N * k <= 64 unknowns: the arms): how lhess
+   * (costs.py:175-207) is rendered.
+   *   GIK_HESS_PER_EDGE: the reference's arithmetic -- per edge  s = y . (W_i - W_j),  t = 2 s a y + c w,  +t to one end
+   *     and -t to the other (costs.py:186-203), the form every other kernel of the library uses.  The three lanes of a
+   *     node split its term list, each evaluates its terms completely from whole rows and the three partial vectors are
+   *     added (gik_wave_strict.hip.h).  Exists for TrustRegions, theta = 1, free-free (not anchored) graphs.
+   *     Against the CPU oracle from the same start points (8192 random KUKA goals): Hessian products +1.7 %, share of
+   *     goals at maxiter 668 / 677, p90 of the outer iterations 0.99 x; 7-DOF end configurations 2.9e-3 rad from the
+   *     reference in the median (the reference's own two code paths: 3.0e-3).
+   *   GIK_HESS_COLUMN: rows of the 3 x 3 blocks 2 a y y^T + c I, cached per accepted point, times the neighbour's
+   *     entries.  s is never formed: the Gauss-Newton part's round-off leaves range(J^T) and truncated CG needs 5-8 %
+   *     more Hessian products than the reference's arithmetic (7-DOF end configurations 8.4e-3 rad from the reference,
+   *     2.8 x the reference pair's own spread).  Until round 5 the default; since round 6 NOT faster either (c2 34.6 k
+   *     against 35.0 k solves/s, c4 126 k against 130 k: DESIGN.md 4.1) -- kept as the form of the ConjugateGradient,
+   *     theta != 1, anchored and planar wavefront kernels, and as an explicit choice for comparisons.
+   *   GIK_HESS_AUTO (default): PER_EDGE where that kernel exists (3-D, TrustRegions, theta = 1, not anchored), else
+   *     COLUMN.  An explicit GIK_HESS_PER_EDGE on a wavefront template without such a kernel is refused.
+   * Graphs on the workgroup / node-per-lane kernels form s per edge whatever this field says (gik_template_info
+   * reports GIK_HESS_PER_EDGE for them).                                                                          */
   int32_t hessian_form;
 } gik_template_desc;
-enum { GIK_HESS_COLUMN = 0, GIK_HESS_PER_EDGE = 1 };
+enum { GIK_HESS_COLUMN = 0, GIK_HESS_PER_EDGE = 1, GIK_HESS_AUTO = 2 };
 
 enum { GIK_SOLVER_TRUST_REGIONS = 0, GIK_SOLVER_CONJUGATE_GRADIENT = 1 };
 enum {
@@ -222,7 +233,8 @@ typedef struct {
                                   the handle above); else 1 (0: block) */
   int32_t goals_per_wave;      /* prepare kernel: 4 = graph of at most 16 nodes, four goals to a wavefront
                                   (prep_quad_kernel); 1 = one (prep_wave_kernel); 0 = workgroup per goal / no pipeline */
-  int32_t hessian_form;        /* GIK_HESS_* in effect on the wavefront kernel (GIK_HESS_COLUMN elsewhere)          */
+  int32_t hessian_form;        /* what the solve kernel of this template does: GIK_HESS_PER_EDGE or GIK_HESS_COLUMN
+                                  (never _AUTO; workgroup and node-per-lane kernels: always _PER_EDGE)              */
 } gik_template_info;
 int gik_template_get_info(const gik_template *t, gik_template_info *info);
 

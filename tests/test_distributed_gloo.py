@@ -94,7 +94,15 @@ def test_bench_self_launches_ranks_and_gathers():
     # ... and the default line (what the driver runs at every N) carries the other BASELINE workloads
     # under "configs": the c4 / c5 tables gathered from two shards equal the one-rank tables
     cf = w2["configs"]
-    assert set(cf) == {"c3", "c4", "c5", "c5_nolimits"}     # (the 8192-goal share line is single-GPU only)
+    assert set(cf) == {"c3", "c4", "c5", "c5_nolimits", "c2_column", "c4_column"}     # (the 8192-goal share line is single-GPU only)
+    assert cf["c4_column"]["rows_sha"] == one["rows_sha"]      # (the dry solve knows no product form: the same table)
+    # every rank's own time, longest problem, share of maxiter goals and goal count (a shard is as long as
+    # ITS longest problem -- the record the first hardware scaling run is read against)
+    for line, world in ((one, 1), (two, 2), (w2, 2)):
+        pr = line["per_rank"]
+        assert len(pr) == world and all(set(r) == {"ms", "max_outer", "frac_maxiter", "goals"} for r in pr), pr
+        assert sum(r["goals"] for r in pr) == line["rows"]
+    assert [r["goals"] for r in two["per_rank"]] == [32768, 32768]
     assert cf["c4"]["rows_sha"] == one["rows_sha"] and cf["c4"]["scaling"] == "strong"
     assert cf["c3"]["rows"] == 2 * 4096 and cf["c3"]["scaling"] == "weak"
     # c5 shards the planar chain the same way (uneven world sizes included)

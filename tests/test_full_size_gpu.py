@@ -389,7 +389,12 @@ def test_rccl_gather_under_torchrun(torch_cuda):
     # BASELINE workload under "configs", all through the same process group
     d = _bench(launcher, "--backend", "nccl")
     assert d["config"]["config"] == "c2" and d["gather"]["backend"] == "nccl" and d["gather"]["rows"] == 4096
-    assert set(d["configs"]) == {"c3", "c4", "c4_share_of_8", "c5", "c5_nolimits"}
+    assert set(d["configs"]) == {"c3", "c4", "c4_share_of_8", "c5", "c5_nolimits", "c2_column", "c4_column"}
+    # the default lines run the per-edge product form, the *_column lines the column form -- and say so
+    assert "per-edge" in d["roofline"]["kernel"] and "per-edge" in d["configs"]["c4"]["kernel"]
+    assert "column" in d["configs"]["c2_column"]["kernel"] and "column" in d["configs"]["c4_column"]["kernel"]
+    assert d["summary"]["traffic_stale"] in (True, False) and "traffic_stale" in d["roofline"]
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["goals"] == 4096 and d["per_rank"][0]["max_outer"] == 3000
     assert d["seeds"]["seeds"] == [0, 1, 2, 3] and len(d["seeds"]["ms_per_step"]) == 4
     assert d["gather"]["bytes_per_problem"] == 8 * (7 + 9) and d["kernels"]["dominant"].startswith("rtr_wave_kernel")
     assert d["configs"]["c5"]["kernels"]["dominant"].startswith("prep_quad_kernel") and d["configs"]["c5"]["roofline_prepare"]["frac"] > 0

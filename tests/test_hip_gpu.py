@@ -35,9 +35,12 @@ def test_cost_grad_hess_proj_known_answers(torch_cuda, name):
     from oracle import c_oracle as co
     d = load_golden(name)
     templates = [_template(d)] + ([_template(d, debug_flags=16384)] if int(d["dim"]) == 2 else
-                                  [_template(d, hessian_form=1)])      # (3-D: + the per-edge product form, WaveCtxStrict)
+                                  [_template(d, hessian_form="column")])      # (3-D: + the column-form product, WaveCtx)
     if int(d["dim"]) == 3:
-        assert templates[1].info["hessian_form"] == 1 and templates[0].info["hessian_form"] == 0
+        # the default of a 3-D wavefront graph is the reference's per-edge arithmetic (WaveCtxStrict); graphs on the
+        # workgroup / node-per-lane kernels (the table scene) form s per edge whatever the field says
+        blk = templates[0].info["is_block"]
+        assert templates[0].info["hessian_form"] == 1 and templates[1].info["hessian_form"] == (1 if blk else 0)
     for T in templates:
         key = "lim" if int(d["use_limits"]) else "nolim"
         tg = T.targets_from_D(d["D_goal"][0])
@@ -149,9 +152,10 @@ def test_trajectory_planar_identical_to_oracle(torch_cuda, name, per_wave):
     assert exact_tail >= len(d["seed"]) // 2
 
 
-# the 3-D solve kernels: wavefront (column-form product, the default), wavefront with the per-edge product form
-# (gik_template_desc.hessian_form = GIK_HESS_PER_EDGE, round 5), workgroup, node-per-lane
-_PATH_PARAMS = {"wave": {"force_block_path": 0}, "wave_per_edge": {"force_block_path": 0, "hessian_form": 1},
+# the 3-D solve kernels: wavefront (the default: the per-edge product form, costs.py:186-203 term by term), wavefront with
+# the column-form product (gik_template_desc.hessian_form = GIK_HESS_COLUMN, the default until round 5), workgroup,
+# node-per-lane
+_PATH_PARAMS = {"wave": {"force_block_path": 0}, "wave_column": {"force_block_path": 0, "hessian_form": "column"},
                 "block": {"force_block_path": 1}, "npt": {"force_block_path": 2}}
 
 
@@ -163,7 +167,7 @@ def _hip_traces(d, path):
     return r, [{k: tr[k][g] for k in tr} for g in range(len(d["seed"]))]
 
 
-@pytest.mark.parametrize("path", ["wave", "wave_per_edge", "block", "npt"])
+@pytest.mark.parametrize("path", ["wave", "wave_column", "block", "npt"])
 @pytest.mark.parametrize("name", SCENARIOS_3D)
 def test_trajectory_prefix_3d(torch_cuda, name, path):
     """identical discrete decisions and f, |grad| to 1e-8 for the outer iterations
@@ -216,7 +220,7 @@ def test_trajectory_prefix_3d(torch_cuda, name, path):
     assert k_hip.sum() >= 0.85 * k_ref.sum(), (k_hip, k_ref)
 
 
-@pytest.mark.parametrize("path", ["wave", "wave_per_edge", "block", "npt"])
+@pytest.mark.parametrize("path", ["wave", "wave_column", "block", "npt"])
 @pytest.mark.parametrize("name", SCENARIOS_3D)
 def test_finals_statistical_3d(torch_cuda, name, path):
     """End-to-end parity of the recovered joint configurations (same IK branch,
@@ -272,8 +276,8 @@ def test_finals_statistical_3d(torch_cuda, name, path):
         # isolated solutions: pointwise.  Wherever the reference's two paths agree to 1e-3, so does HIP
         for g in range(nl):
             if dq_ref[g] < 1e-3 and conv[g]:
-                assert dq[g] < (1e-3 if path == "wave" else 5e-3), (g, dq[g], dq_ref[g])
-        if path == "wave":
+                assert dq[g] < (1e-3 if path == "wave_column" else 5e-3), (g, dq[g], dq_ref[g])
+        if path == "wave_column":
             assert np.all(dq[conv] < 1e-3), dq
         else:
             assert np.mean(dq[conv] < 1e-3) >= 0.9 and np.all(dq[conv] < 5e-3), dq
@@ -285,7 +289,7 @@ def test_finals_statistical_3d(torch_cuda, name, path):
         # upper quartile against the upper quartile:
         both = conv & (d["loop_f_sol"] < 1e-9)
         for qt in (50, 75):
-            bar = (3 if path == "wave" else 2) * max(np.percentile(dq_orc[conv], qt), np.percentile(dq_ref[both], qt))
+            bar = (3 if path == "wave_column" else 2) * max(np.percentile(dq_orc[conv], qt), np.percentile(dq_ref[both], qt))
             assert np.percentile(dq[conv], qt) <= bar, (qt, np.percentile(dq[conv], qt), bar)
         # nothing beyond the self-motion scale, except on goals where the oracle or the reference's OWN second path
         # leaves the numpy path's branch as well (LWA4D goal 14: reference pair 0.195 rad apart, node-per-lane
@@ -322,7 +326,7 @@ def test_gradient_roundoff_is_horizontal(torch_cuda, name):
         assert np.abs(G[b].sum(axis=0)).max() < 1e-12 * nrm   # translation-free as well
 
 
-@pytest.mark.parametrize("path", ["wave", "wave_per_edge", "block", "npt"])
+@pytest.mark.parametrize("path", ["wave", "wave_column", "block", "npt"])
 def test_effort_parity_ur10(torch_cuda, path):
     """Same work as the reference's algorithm, not only the same answers: on random UR10 goals no
     tCG solve runs into maxinner (the reference's never do; a search direction that keeps the
@@ -339,7 +343,7 @@ def test_effort_parity_ur10(torch_cuda, path):
     robot, graph = make_graph("ur10")
     prob = BatchProblem(graph, use_limits=True, params=_PATH_PARAMS[path])
     assert prob.template.info["is_block"] == int(not path.startswith("wave"))
-    assert prob.template.info["hessian_form"] == int(path == "wave_per_edge")
+    assert prob.template.info["hessian_form"] == int(path != "wave_column")
     B = 192
     rng = np.random.RandomState(3)
     Tg = robot.fk_batch(-np.pi + 2 * np.pi * rng.rand(B, robot.n))
@@ -355,44 +359,59 @@ def test_effort_parity_ur10(torch_cuda, path):
     hv_o = np.array([x["inner_total"] for x in o])
     assert np.array_equal(its < 3000, its_o < 3000)
     assert 0.9 < np.median(its) / np.median(its_o) < 1.1
-    assert 0.95 < hv.sum() / hv_o.sum() < (1.12 if path == "wave" else 1.06), (hv.sum(), hv_o.sum())
+    assert 0.95 < hv.sum() / hv_o.sum() < (1.12 if path == "wave_column" else 1.06), (hv.sum(), hv_o.sum())
 
 
-@pytest.mark.parametrize("path", ["wave", "wave_per_edge", "block", "npt"])
+_TAIL_ORACLE = {}
+
+
+@pytest.mark.parametrize("path", ["wave", "wave_column", "block", "npt"])
 def test_effort_parity_kuka_tail(torch_cuda, path):
-    """The TAIL of the effort distribution on the redundant arm: 8 % of KUKA goals run to maxiter and
-    hold a third of c4's Hessian products, so p90 of the outer iterations is where parity and throughput meet.
-    512 random goals, oracle from the device's start points.  The per-edge product form (hessian_form = 1) sits ON the
-    oracle: p90(outer iterations) measured 1.01x, bar 1.08x (the judge's 1.15x with room to spare).  The default column
-    form does NOT meet 1.15x: measured 1.07x / 1.18x / 1.19x on 512 / 384 / 1024 goals (p90 lies on the cliff next to
-    the 8 % of goals that run to maxiter, so the sample moves it) -- it is held to 1.25x, and kept as the default
-    because the per-edge form costs 8.0 % (c2) / 8.9 % (c4) of the throughput (VERDICT r4's own rule: default
-    only below 8 % of c4).  The workgroup and node-per-lane kernels -- which an 18-node arm only runs on when forced -- carry the
-    heaviest tail (1.25x / 1.24x, profiles/r05_parity_by_kernel_path.json): 1.35x.  Same convergence class on >= 93 %
-    of the goals; Hessian products within +8 % (column) / +4 % (per edge) / +7 %."""
+    """The TAIL of the effort distribution on the redundant arm: 8.3 % of KUKA goals run to maxiter and
+    hold a third of c4's Hessian products, so the share of such goals is where parity and throughput meet.
+    8192 random goals, oracle from the device's start points.
+
+    Rounds 4-5 measured p90 of the outer iterations on 512 goals and found 1.25x on the workgroup, node-per-lane and
+    (round 6, first run) the new per-edge wavefront kernels against 1.01x for round 5's per-edge form.  Round 6 bisected
+    it (tools/tail_bisect.py, tools/exp/strict_bisect.sh, NOTEBOOK 11.2): with p90 sitting 1.7 % of the goals away
+    from the 8.3 % that stop at 3000, a surplus of nine goals in 512 moves it by 450 iterations -- and between any two
+    correct renderings of the same arithmetic ~3.5 % of the goals change class, in BOTH directions.  On 8192 goals
+    every summation grouping of gradient, product and cost (fourteen builds) and every kernel path has the oracle's
+    share of maxiter goals to within the binomial noise of the flips: wavefront default 668 / 677 (to / from maxiter
+    142 / 151), column 695 (152 / 134), workgroup 691 (145 / 131), node-per-lane 696 (154 / 135); p90 0.99x / 1.005x /
+    1.05x / 1.02x.  So the statistics here are the ones that have a noise model: the flips must be balanced to three
+    standard deviations, p90 and p75 within the bars on a sample where p90 is resolved (+-4 %), Hessian products
+    within +4 % (column form: +8 %; measured +1.7 / +5.2 / +1.9 / +1.1 %)."""
     from oracle import c_oracle as co
     from graphik_amd.engine import Template
     from graphik_amd.solvers.riemannian_solver import BatchProblem
     from parity_util import report
     robot, graph = make_graph("kuka")
     prob = BatchProblem(graph, use_limits=True)
-    B = 512
+    B = 8192
     rng = np.random.RandomState(3)
     Tg = robot.fk_batch(-np.pi + 2 * np.pi * rng.rand(B, robot.n))
     targets, Y0 = prob.prepare(Tg)
-    D, _, _ = prob.assemble(Tg)
-    o = co.rtr_solve_batch(np.asarray(Y0), D, prob.omega, prob.psi_L, prob.psi_U, True, fast=False)
+    if "o" not in _TAIL_ORACLE:
+        D, _, _ = prob.assemble(Tg)
+        _TAIL_ORACLE["o"] = co.rtr_solve_batch(np.asarray(Y0), D, prob.omega, prob.psi_L, prob.psi_U, True, fast=False)
+    o = _TAIL_ORACLE["o"]
     T = Template.from_matrices(prob.omega, prob.psi_L, prob.psi_U, k=3, use_limits=True, params=_PATH_PARAMS[path])
     r = T.solve(Y0, targets)
     its, hv = r["iterations"].cpu().numpy(), r["inner_total"].cpu().numpy().astype(np.int64)
+    mx, mxo = its >= 3000, o["iterations"] >= 3000
+    to, frm = int((mx & ~mxo).sum()), int((~mx & mxo).sum())
     p90, p90_o = np.percentile(its, 90), np.percentile(o["iterations"], 90)
-    same = np.mean((its < 3000) == (o["iterations"] < 3000))
+    p75, p75_o = np.percentile(its, 75), np.percentile(o["iterations"], 75)
     hvr = hv.sum() / o["inner_total"].sum()
-    report(f"effort_tail/kuka/{path}", {"p90_outer": [float(p90), float(p90_o)], "same_class": float(same), "hv_ratio": float(hvr)})
-    bar = {"wave": 1.25, "wave_per_edge": 1.08}.get(path, 1.35)
-    assert p90 <= bar * p90_o, (p90, p90_o)
-    assert same >= 0.93, same
-    assert 0.95 < hvr < {"wave": 1.08, "wave_per_edge": 1.04}.get(path, 1.07), hvr
+    report(f"effort_tail/kuka/{path}", {"goals": B, "p90_outer": [float(p90), float(p90_o)], "p75_outer": [float(p75), float(p75_o)],
+                                        "at_maxiter": [int(mx.sum()), int(mxo.sum())], "to_maxiter": to, "from_maxiter": frm,
+                                        "same_class": float(np.mean(mx == mxo)), "hv_ratio": float(hvr)})
+    assert abs(to - frm) <= 3.0 * np.sqrt(to + frm) + 1, (to, frm)        # no systematic drift into (or out of) maxiter
+    assert np.mean(mx == mxo) >= 0.95
+    assert p90 <= {"wave": 1.06, "wave_column": 1.08}.get(path, 1.10) * p90_o, (p90, p90_o)
+    assert 0.95 * p75_o <= p75 <= 1.05 * p75_o, (p75, p75_o)
+    assert 0.97 < hvr < (1.08 if path == "wave_column" else 1.04), hvr
 
 
 # ---- batched pipeline -------------------------------------------------------------------------
@@ -1802,6 +1821,16 @@ def test_c_abi_error_behaviour(torch_cuda):
     refused(L.gik_template_create(C.byref(desc(N=256)), C.byref(h)), "N must be")      # (round 5: up to 255)
     refused(L.gik_template_create(C.byref(desc(N=129, k=2)), C.byref(h)), "128 nodes")  # beyond 128: 3-D TrustRegions only
     refused(L.gik_template_create(C.byref(desc(hessian_form=3)), C.byref(h)), "hessian_form")
+    # an explicit per-edge product where no such kernel exists (ConjugateGradient, theta != 1) is refused, not ignored ...
+    refused(L.gik_template_create(C.byref(desc(hessian_form=_ffi.HESS_PER_EDGE, solver=_ffi.SOLVER_CONJUGATE_GRADIENT)), C.byref(h)), "GIK_HESS_PER_EDGE")
+    refused(L.gik_template_create(C.byref(desc(hessian_form=_ffi.HESS_PER_EDGE, theta=0.5)), C.byref(h)), "GIK_HESS_PER_EDGE")
+    # ... while the default (GIK_HESS_AUTO) resolves to what the template's kernel does, and says so
+    info = _ffi.TemplateInfo()
+    for kw, form in (({}, _ffi.HESS_PER_EDGE), ({"theta": 0.5}, _ffi.HESS_COLUMN), ({"solver": _ffi.SOLVER_CONJUGATE_GRADIENT}, _ffi.HESS_COLUMN),
+                     ({"hessian_form": _ffi.HESS_COLUMN}, _ffi.HESS_COLUMN), ({"force_block_path": 1}, _ffi.HESS_PER_EDGE)):
+        assert L.gik_template_create(C.byref(desc(**kw)), C.byref(h)) == 0, L.gik_last_error()
+        assert L.gik_template_get_info(h, C.byref(info)) == 0 and info.hessian_form == form, (kw, info.hessian_form)
+        L.gik_template_destroy(h)
     refused(L.gik_template_create(C.byref(desc(n_terms=0)), C.byref(h)), "n_terms")
     refused(L.gik_template_create(C.byref(desc(solver=7)), C.byref(h)), "solver")
     refused(L.gik_template_create(C.byref(desc(clique_closed_form=9)), C.byref(h)), "clique_closed_form")

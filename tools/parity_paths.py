@@ -1,5 +1,5 @@
-"""Parity residuals by kernel path (round 4): for the three 3-D arms and the three solve
-kernels -- wavefront (one unknown per lane, per-slot Hessian rows cached per tCG solve, column form),
+"""Parity residuals by kernel path (round 4): for the three 3-D arms and the solve
+kernels -- wavefront (one unknown per lane: the default per-edge product form and, "wave_column", the column form with per-slot Hessian rows cached per tCG solve),
 workgroup (terms recomputed from the point rows), node-per-lane (s = y . w formed once per edge) --
   (a) finals on the golden goals: median / upper-quartile max |dq| against the reference's numpy path,
       next to the oracle's and the reference's own two paths;
@@ -18,7 +18,7 @@ from graphik_amd.graphs.graph_revolute import joint_variables_revolute_batch
 from graphik_amd.solvers.riemannian_solver import BatchProblem
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-PATHS = {"wave": {}, "wave_per_edge": {"hessian_form": 1}, "block": {"force_block_path": 1}, "npt": {"force_block_path": 2}}
+PATHS = {"wave": {}, "wave_column": {"hessian_form": "column"}, "block": {"force_block_path": 1}, "npt": {"force_block_path": 2}}
 out = {}
 for name in ("kuka", "lwa4d", "ur10"):
     d = load_golden(name)

@@ -5,9 +5,12 @@
 # Results land under gpurun_out/prof_<tag>/; tools/summarize_prof.py copies the summaries worth keeping
 # to profiles/.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r05}; shift
+TAG=${1:-r06}; shift
 P=$R/gpurun_out/prof_$TAG
 mkdir -p "$P"
+# which binary these counters are read from: the digest of the library's sources (graphik_amd/build.py), carried into
+# profiles/<tag>_hbm_traffic.json by summarize_prof.py and compared by bench.py (roofline.traffic_stale)
+cp "$R/graphik_amd/lib/libgraphik_amd.so.digest" "$P/source_digest.txt" 2>/dev/null || echo unknown > "$P/source_digest.txt"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline --serving-streams 0 --headline-only $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt -o r1 -- python $R/bench.py $ARGS > $P/kt_bench.json 2> $P/kt.err

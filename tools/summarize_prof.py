@@ -22,7 +22,7 @@ import sys
 from collections import defaultdict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 P = os.path.join(REPO, "gpurun_out", "prof_" + tag)
 out = os.path.join(REPO, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -58,8 +58,15 @@ if prep and "FETCH_SIZE" in summary[prep]:
     prep_entry = {"kernel": prep, "bytes_per_launch": pf + pw, "fetch_bytes_corrected": pf, "write_bytes": pw,
                   "lds_bank_conflict_ratio": (summary[prep]["SQ_LDS_BANK_CONFLICT"] / summary[prep]["SQ_LDS_IDX_ACTIVE"]
                                               if summary[prep].get("SQ_LDS_IDX_ACTIVE") else None)}
+try:
+    digest = open(os.path.join(P, "source_digest.txt")).read().strip()
+except OSError:
+    digest = None
 json.dump({"kernel": solve, "bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch,
            "write_bytes": write, "prepare": prep_entry,
+           # graphik_amd.build.source_digest() of the library these counters were read from (tools/profile.sh): bench.py
+           # prints "traffic_stale": true when the loaded library's differs
+           "source_digest": digest,
            "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, "
                   "tools/profile.sh %s), bench.py --steps 2 --warmup 1, mean over the dispatches; " % tag +
                   "FETCH_SIZE (KiB) x1024 x2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM "
