@@ -227,6 +227,16 @@ static hipError_t raise_dynamic_lds(const void *fn, size_t bytes) {
   return e;
 }
 
+static bool capturing_stream(void *stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (!stream) return false;      // (the null stream cannot capture)
+  if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return st != hipStreamCaptureStatusNone;
+}
+
 template <typename T>
 static const T *upload(gik_template *t, const T *host, size_t count, bool &ok) {
   if (count == 0 || !host) return nullptr;
@@ -1101,6 +1111,8 @@ int gik_prepare_batch_debug(const gik_template *t, const double *d_T_goal, int B
   if (!t->has_pipe) return fail("no pipeline attached (gik_pipeline_attach)");
   if (B == 0) return 0;
   if (!d_T_goal || !d_targets || !d_Y_init) return fail("null buffer");
+  if (t->prep_block && capturing_stream(stream))      // (the workgroup variant chains its launches by an event)
+    return fail("gik_prepare_batch: the stream is capturing (hipStreamBeginCapture); batch calls cannot be captured into a graph");
   PrepArgs a;
   a.pc = t->pc;
   a.T_goal = d_T_goal;
@@ -1385,20 +1397,18 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   // that no other call holds.  The lock covers the hand-out only: waiting for a slot's previous user, growing
   // its workspace (hipEventSynchronize / hipFree / hipMalloc) and the launch happen outside it, on a slot
   // marked in_use.
-  // (hipEventQuery is not allowed while a stream captures: a capturing caller skips the warm-slot test)
-  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
-  if (stream && hipStreamIsCapturing((hipStream_t)stream, &cap_status) != hipSuccess) {
-    (void)hipGetLastError();
-    cap_status = hipStreamCaptureStatusNone;
-  }
-  const bool capturing = cap_status != hipStreamCaptureStatusNone;
+  // Stream capture is refused: the slot protocol below queries, waits for and records events, grows workspaces
+  // (hipMalloc / hipFree) and resets a counter the kernel consumes -- none of which may happen under capture, and a
+  // replayed graph would reuse this call's counter slot and workspace behind the library's back.  A batch is ONE
+  // persistent launch; there is no launch overhead for a graph to remove.
+  if (capturing_stream(stream)) return fail("gik_solve_batch: the stream is capturing (hipStreamBeginCapture); batch calls cannot be captured into a graph");
   auto take = [&](auto &slots, unsigned &next, unsigned n) -> int {
     for (;;) {
       {
         std::lock_guard<std::mutex> lock(mt->call_mutex);
         const unsigned last = (next + n - 1) % n;
         auto &ls = slots[last];
-        if (!ls.in_use && ls.done && (!ls.pending || (!capturing && hipEventQuery(ls.done) == hipSuccess))) {
+        if (!ls.in_use && ls.done && (!ls.pending || hipEventQuery(ls.done) == hipSuccess)) {
           ls.pending = false;
           ls.in_use = true;
           return (int)last;

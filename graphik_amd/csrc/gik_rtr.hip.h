@@ -254,6 +254,12 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         const double nr0_theta = (THETA_ONE || p.theta == 1.0) ? norm_grad : pow(norm_grad, p.theta);
         const double target = norm_grad * fmin(nr0_theta, p.kappa);  // rhs of :572
         const double target2 = target * target;
+        // The residual test (:572) is taken on the PREDICTED <r', r'>.  Where the prediction comes within 1e-9 of the
+        // threshold the decision would hang on the prediction's own round-off, so the hot path only continues on a
+        // clear miss (> target2_hi); anything nearer goes through the cold block, which re-sums <r', r'> as the
+        // reference does (:560-572) when the value lies inside the band -- a second reduction on a few steps in a
+        // thousand, no instruction in the hot path.  (Until round 5 this was the one tolerated early flip.)
+        const double target2_hi = target2 * (1.0 + 1e-9), target2_lo = target2 * (1.0 - 1e-9);
         // radius the plain path tests against: Delta2 / 16 until the checkpoint is taken
         const double Tq = 0.0625 * Delta2;
         double T_cur = RETRACE ? Tq : Delta2;
@@ -323,9 +329,10 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
           // (the last permitted iteration, :495, is routed through the cold block as well, so
           // that the loop has a single exit edge)
           const bool plain = (model_value < model_prev) & (d_Hd > 0.0) & (e_Pe_new < T_cur) &
-                             (beta_p >= 1e-3) & !((j >= p.mininner) & (new_r_r <= target2)) &
+                             (beta_p >= 1e-3) & !((j >= p.mininner) & (new_r_r <= target2_hi)) &
                              (j + 1 < p.maxinner);
           double beta = beta_p;
+          double rr_test = new_r_r;      // what the residual test sees (the recurrences keep the prediction)
           if (__builtin_expect(UNI(!plain), 0)) {   // any exit, a NaN, or the accuracy guard
             if (!(d_Hd == d_Hd) || !(new_r_r == new_r_r) || !(model_value == model_value)) {
               bad = true;
@@ -372,8 +379,12 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
               const double new_r = fma(alpha_c, Hdelta, r);     // :561
               new_r_r = cx.sum1(new_r * new_r);
               beta = new_r_r / r_r;
+              rr_test = new_r_r;
+            } else if (j >= p.mininner && new_r_r >= target2_lo && new_r_r <= target2_hi) {
+              const double new_r = fma(alpha_c, Hdelta, r);     // :561: a near tie is decided on the sum itself (:564)
+              rr_test = cx.sum1(new_r * new_r);
             }
-            if (j >= p.mininner && new_r_r <= target2) {        // :572
+            if (j >= p.mininner && rr_test <= target2) {        // :572
               e_Pe_end = e_Pe_new;   // this step passed the radius test (what a rerun has to pass again)
               // the reference tests the model of this step first (:552)
               const double new_eta = fma(alpha_c, delta, ec);   // :538

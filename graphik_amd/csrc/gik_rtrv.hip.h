@@ -115,6 +115,7 @@ __device__ inline void rtr_solve_vec(Ctx &cx, const Params &p, const gik_trace &
       const double nr0_theta = (THETA_ONE || p.theta == 1.0) ? norm_grad : pow(norm_grad, p.theta);
       const double target = norm_grad * fmin(nr0_theta, p.kappa);  // rhs of :572
       const double target2 = target * target;
+      const double target2_hi = target2 * (1.0 + 1e-9), target2_lo = target2 * (1.0 - 1e-9);   // (see rtr_solve_one)
       const double Tq = 0.0625 * Delta2;         // radius the plain path tests against until the checkpoint
       double T_cur = Tq;
       ck_set = false;
@@ -186,9 +187,10 @@ __device__ inline void rtr_solve_vec(Ctx &cx, const Params &p, const gik_trace &
         const double beta_p = fma(fma(alpha, Hd_Hd, -(v[4] + v[4])), rho, 1.0);      // :592 predicted
         double new_r_r = beta_p * r_r;                                               // :564 predicted
         const bool plain = (model_value < model_prev) & (d_Hd > 0.0) & (e_Pe_new < T_cur) &
-                           (beta_p >= 1e-3) & !((j >= p.mininner) & (new_r_r <= target2)) &
+                           (beta_p >= 1e-3) & !((j >= p.mininner) & (new_r_r <= target2_hi)) &
                            (j + 1 < p.maxinner);
         double beta = beta_p;
+        double rr_test = new_r_r;      // what the residual test sees (the recurrences keep the prediction)
         if (__builtin_expect(UNI(!plain), 0)) {   // any exit, a NaN, or the accuracy guard
           if (!(d_Hd == d_Hd) || !(new_r_r == new_r_r) || !(model_value == model_value)) {
             bad = true;
@@ -242,8 +244,17 @@ __device__ inline void rtr_solve_vec(Ctx &cx, const Params &p, const gik_trace &
             }
             new_r_r = cx.sum1(s);
             beta = new_r_r / r_r;
+            rr_test = new_r_r;
+          } else if (j >= p.mininner && new_r_r >= target2_lo && new_r_r <= target2_hi) {
+            double s = 0.0;      // a near tie is decided on the sum itself (:560-572)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+              const double nr = fma(alpha_c, Hdelta[e], r[e]);
+              s = fma(nr, nr, s);
+            }
+            rr_test = cx.sum1(s);
           }
-          const bool at_target = j >= p.mininner && new_r_r <= target2;           // :572
+          const bool at_target = j >= p.mininner && rr_test <= target2;           // :572
           const bool at_maxinner = j + 1 >= p.maxinner;                           // :495
           if (at_target || at_maxinner) {
             e_Pe_end = e_Pe_new;   // this step passed the radius test (what a rerun has to pass again)

@@ -177,6 +177,15 @@ def solve_batch_sharded(graph, T_goals, use_limits=True, params=None, with_Y=Fal
     else:
         from .solvers.riemannian_solver import _problem_for, solve_batch
         prob = _problem_for(graph, use_limits, params, None)
+        # The one place where the SIZE of a call selects arithmetic: planar graphs of at most 16 nodes run four problems
+        # to a wavefront from 12 problems per CU on, one below (include/graphik_amd.h).  A rank sees only its shard, so
+        # the rule is applied here to the GLOBAL batch and pinned (debug_flags 16384 / 8192): the gathered table then
+        # does not depend on the world size.
+        info = prob.template.info
+        if info.get("problems_per_wave") == 4 and not (int((params or {}).get("debug_flags", 0)) & (8192 | 16384)):
+            pin = 16384 if B >= 12 * int(info["n_cu"]) else 8192
+            pinned = dict(params or {}, debug_flags=int((params or {}).get("debug_flags", 0)) | pin)
+            prob = _problem_for(graph, use_limits, pinned, None)
         dev = torch.device("cpu") if cpu_group else prob.template.device
         if prob.device_pipeline:          # prepare -> solve -> recover on the device, results stay there
             res = prob.template.ik(torch.from_numpy(np.ascontiguousarray(T)).to(prob.template.device))

@@ -146,13 +146,19 @@ enum {
  *     are chained by an event (they serialise; results are unaffected);
  *   - anchored templates: the event pair read by gik_anchored_last_solve_ms (diagnostic; with
  *     concurrent callers it reports whichever call recorded last).
- * Results never depend on any of it.  ONE thing about a call does select arithmetic: planar graphs of at most 16
- * nodes run four problems to a wavefront (rtr_quad_kernel: the k = 2 projector by substitution, inner products summed
- * per node first) in batches of at least 12 problems per CU and one problem per wavefront below that, so the same goal
- * can come back with different last bits (x agrees to ~1e-9, iteration counts on 100 %, inner_total on 99.3 % of
- * 65536 goals) depending on how many goals share the call -- or, with solve_batch_sharded, on the world size.
- * debug_flags 16384 / 8192 pin the four-problem / one-problem kernel at every batch size.  Destroying a handle while
- * calls on it are in flight is undefined; synchronise first.                                          */
+ * Because of that bookkeeping a batch call cannot be captured into a HIP graph: on a stream that is capturing
+ * (hipStreamBeginCapture) gik_solve_batch / gik_ik_batch / gik_anchored_ik_batch -- and gik_prepare_batch where it
+ * uses the workgroup kernel -- return an error before touching the stream.  (A batch is one persistent launch; there
+ * is no launch overhead for a graph to remove.)
+ * Results never depend on that bookkeeping, on the stream, on the number of calls in flight or on how the problems of
+ * a batch are scheduled.  ONE property of a call does select arithmetic, and it is the number of goals in it: planar
+ * graphs of at most 16 nodes run four problems to a wavefront (rtr_quad_kernel: the k = 2 projector by substitution,
+ * inner products summed per node first) in batches of at least 12 problems per CU and one problem per wavefront below
+ * that, so the same goal can come back with different last bits (x agrees to ~1e-9, iteration counts on 100 %,
+ * inner_total on 99.3 % of 65536 goals) depending on how many goals share the call.  debug_flags 16384 / 8192 pin the
+ * four-problem / one-problem kernel at every batch size; graphik_amd.distributed.solve_batch_sharded applies the rule
+ * to the GLOBAL batch and pins the result, so what it gathers does not depend on the world size.  Destroying a handle
+ * while calls on it are in flight is undefined; synchronise first.                                          */
 typedef struct gik_template gik_template;
 
 /* Per-problem solver statistics (final_values of the reference's optlog + counters). */

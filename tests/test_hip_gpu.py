@@ -176,10 +176,19 @@ def test_trajectory_prefix_3d(torch_cuda, name, path):
       (1) strictly -- decisions identical, f / |grad| to 1e-8 against the oracle -- up to
           min(20, K12), K12 = first iteration at which the reference's numpy path (fixture) and the
           oracle (the costs.py loops restated) differ by more than 1e-12, i.e. while they are still
-          the same computation; never fewer than 5 iterations.  At most ONE goal per robot may
-          flip a discrete decision earlier (a tCG stopping test decided within round-off: the
-          single-reduction loop predicts |r'|^2 instead of re-summing it -- measured: 1 of 40
-          goals), with f and |grad| still equal to 1e-8 at the flip;
+          the same computation; never fewer than 5 iterations.  On the default kernel NO goal may
+          flip a discrete decision earlier.  (Until round 5 one per robot was tolerated everywhere
+          and blamed on the predicted |r'|^2 of the single-reduction loop.  Round 6 (a) decides a
+          near tie of the residual test on the re-summed value, as trust_region.py:560-572 does
+          (rtr_solve_one: target2_lo / target2_hi), and (b) looked at the one flip there is -- KUKA
+          goal 8, outer iteration 7, column-form and workgroup kernels: the RADIUS test
+          |eta + alpha delta|^2 >= Delta^2 (:506-509), which the reference itself takes on a
+          recurrence, falls one inner iteration earlier (27: exceeded the radius, instead of 28:
+          negative curvature); both end on the same boundary point, the step is rejected either
+          way, f / |grad| / Delta stay equal.  No arithmetic that differs from numpy's in the last
+          bit can promise the reference's side of such a tie, so on the other kernels ONE flip per
+          robot is accepted IF it is exactly that: both solves stop at the trust-region boundary,
+          one inner iteration apart, same acceptance);
       (2) in distribution: the HIP trajectory leaves the oracle's (1e-8) no earlier than the
           reference's own numpy path does, for at least 2/3 of the goals, and the summed prefix
           lengths (capped at 20) reach 85 % of the reference pair's."""
@@ -202,12 +211,16 @@ def test_trajectory_prefix_3d(torch_cuda, name, path):
         k_hip.append(min(CONTRACT_K, kh))
         pinned.append(m)
         if kh < m:
-            # a discrete decision that flipped inside the stable prefix: tolerated once per robot
-            # (below), and only as a near-tie -- everything before it, and f / |grad| AT it, agree
+            # a discrete decision that flipped inside the stable prefix (refused below; recorded with the evidence
+            # that it was a near-tie -- everything before it, and f / |grad| AT it, agree)
             early.append((g, kh, m))
             assert_prefix_equal(traces[g], o["traj"], kh)
             assert kh >= 5 and abs(traces[g]["f_before"][kh] - o["traj"]["f_before"][kh]) <= \
                 1e-8 * abs(o["traj"]["f_before"][kh]), (g, kh)
+            # ... and only as a near-tie of the radius test: boundary exits on both sides, one inner iteration apart
+            assert int(traces[g]["stop"][kh]) in (0, 1) and int(o["traj"]["stop"][kh]) in (0, 1), (g, kh)
+            assert abs(int(traces[g]["numit"][kh]) - int(o["traj"]["numit"][kh])) == 1, (g, kh)
+            assert int(traces[g]["accept"][kh]) == int(o["traj"]["accept"][kh]), (g, kh)
         else:
             assert_prefix_equal(traces[g], o["traj"], m)
             assert np.array_equal(traces[g]["numit"][:m], ref["numit"][:m])      # the reference itself
@@ -215,7 +228,7 @@ def test_trajectory_prefix_3d(torch_cuda, name, path):
     report(f"trajectory_prefix/{name}/{path}", {
         "strictly_pinned_iterations": pinned, "hip_leaves_oracle_at": k_hip.tolist(),
         "reference_np_leaves_oracle_at": k_ref.tolist(), "early_decision_flips": early})
-    assert len(early) <= 1, early
+    assert len(early) <= (0 if path == "wave" else 1), early
     assert np.mean(k_hip >= k_ref) >= 2.0 / 3.0, (k_hip, k_ref)
     assert k_hip.sum() >= 0.85 * k_ref.sum(), (k_hip, k_ref)
 
@@ -1785,6 +1798,38 @@ def test_planar_tree_solve_batch(torch_cuda, which):
         q = graph.joint_variables(info["x"])
         dq = np.array([q[j] for j in robot.joint_ids[1:]]) - g("sol_q_sol")[s_]
         assert np.abs(np.mod(dq + np.pi, 2 * np.pi) - np.pi).max() < 1e-8
+
+
+def test_stream_capture_is_refused(torch_cuda):
+    """A batch call on a capturing stream is refused with a message BEFORE anything that is illegal under capture
+    happens (event queries / waits, workspace growth, the counter reset a replay would share: ADVICE r5), the capture
+    itself survives, and the handle works afterwards.  (The C entry point is called directly: nothing of torch's may
+    run between capture_begin and capture_end either.)"""
+    import ctypes as C
+    from graphik_amd import _ffi
+    from graphik_amd.engine import _alloc_stats
+    d = load_golden("lwa4d")
+    T = _template(d)
+    B = 4
+    dev = T.device
+    tg = torch_cuda.as_tensor(np.ascontiguousarray(T.targets_from_D(d["D_goal"][:B])), device=dev)
+    Y0 = torch_cuda.as_tensor(d["Y_init"][:B], device=dev).contiguous()       # [B, N, 3]
+    ref = T.solve(Y0, tg)["x"].clone()
+    out, stats = torch_cuda.empty_like(Y0), _alloc_stats(B, dev)
+    torch_cuda.cuda.synchronize()
+    s = torch_cuda.cuda.Stream()
+    g = torch_cuda.cuda.CUDAGraph()
+    with torch_cuda.cuda.stream(s):
+        g.capture_begin()
+        try:
+            rc = T.lib.gik_solve_batch(T._h, Y0.data_ptr(), tg.data_ptr(), B, out.data_ptr(), stats.data_ptr(), None,
+                                       C.c_void_p(s.cuda_stream))
+            msg = T.lib.gik_last_error().decode()
+        finally:
+            g.capture_end()
+    assert rc != 0 and "capturing" in msg, (rc, msg)
+    torch_cuda.cuda.synchronize()
+    assert torch_cuda.equal(T.solve(Y0, tg)["x"], ref)
 
 
 def test_c_abi_error_behaviour(torch_cuda):
