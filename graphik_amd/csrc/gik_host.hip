@@ -196,6 +196,7 @@ struct gik_template {
   size_t prep_quad_smem = 0;
   int prep_quad_waves_per_cu = 8;
   bool prep_a_lds = false;     // block variant: work matrix in LDS
+  bool prep_big = false;       // block variant for graphs of 129 .. 255 nodes (work matrix in the slab, always compressed)
   bool prep_no_compress = false;   // block variant: full N x N Jacobi even where the Gram matrix is rank deficient
   double *prep_ws = nullptr;   // [n_cu * prep_waves_per_cu][5][N*N] (block variant)
   hipEvent_t prep_done = nullptr;   // block variant: launches share prep_ws, so each one waits
@@ -976,7 +977,8 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   const int N = t->N, K = t->K, n = d->n_joints;
   if (n < 1 || n > 31) return fail("n_joints out of range");
   if (d->n_anchor < 1 || d->n_anchor > PREP_MAXA) return fail("n_anchor must be in [1, 256]");
-  if (N > PREP_MAXN) return fail("the device pipeline handles graphs of up to 128 nodes");
+  if (N > PREP_BIGN - 1 || (N > PREP_MAXN && K != 3))
+    return fail("the device pipeline handles graphs of up to 128 nodes (3-D: 255)");
   if (!d->T0 || !d->p_index || !d->base_lower || !d->base_upper || !d->anchor_index ||
       !d->anchor_pos || !d->pair_i || !d->pair_j || !d->term_src || !d->term_static)
     return fail("null pipeline array");
@@ -1045,25 +1047,29 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   t->prep_block = N > 32 || d->n_anchor > 32 || d->force_block_prepare != 0 ||
                   getenv("GIK_PREP_FORCE_BLOCK") != nullptr;
   t->prep_no_compress = getenv("GIK_PREP_NO_COMPRESS") != nullptr;   // (developer A/B switch, read once, here)
+  t->prep_big = N > PREP_MAXN;      // graphs of 129 .. 255 nodes: prep_block_kernel<false, PREP_BIGN>, six matrices per slab
   if (t->prep_block) {
     int occ = 0;
     // work matrix in LDS when it fits next to the kernel's static arrays (N <= 123), one workgroup per CU
     t->prep_a_lds = false;
     const size_t a_bytes = sizeof(double) * (size_t)N * N;
-    if (!getenv("GIK_PREP_A_GLOBAL") &&
+    if (t->prep_big) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prep_block_kernel<false, PREP_BIGN>, PREP_NT, 0) != hipSuccess)
+        occ = 1;
+    } else if (!getenv("GIK_PREP_A_GLOBAL") &&
         raise_dynamic_lds((const void *)prep_block_kernel<true>, a_bytes) == hipSuccess &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prep_block_kernel<true>, PREP_NT, a_bytes) == hipSuccess &&
         occ >= 1)
       t->prep_a_lds = true;
     else
       (void)hipGetLastError();
-    if (!t->prep_a_lds &&
+    if (!t->prep_a_lds && !t->prep_big &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prep_block_kernel<false>, PREP_NT, 0) != hipSuccess)
       occ = 1;
     occ = std::max(1, std::min(occ, 2));   // 5 N^2 doubles per workgroup: keep the slabs cache-resident
     if (const char *e = getenv("GIK_PREP_WAVES_PER_CU")) occ = std::max(1, atoi(e));
     t->prep_waves_per_cu = occ;
-    const size_t bytes = sizeof(double) * 5 * (size_t)N * N * (size_t)t->n_cu * occ;
+    const size_t bytes = sizeof(double) * (t->prep_big ? 6 : 5) * (size_t)N * N * (size_t)t->n_cu * occ;
     void *ws = nullptr;
     if (hipMalloc(&ws, bytes) != hipSuccess) return fail("cannot allocate the prepare workspace");
     t->pipe_allocs.push_back(ws);
@@ -1135,7 +1141,10 @@ int gik_prepare_batch_debug(const gik_template *t, const double *d_T_goal, int B
     gik_template *mt = const_cast<gik_template *>(t);   // the workspace hand-over is the mutable part
     std::lock_guard<std::mutex> lock(mt->prep_mutex);
     if (mt->prep_pending) HIP_OK(hipStreamWaitEvent((hipStream_t)stream, mt->prep_done, 0));
-    if (t->prep_a_lds)
+    if (t->prep_big)
+      hipLaunchKernelGGL((prep_block_kernel<false, PREP_BIGN>), dim3(grid), dim3(PREP_NT), 0, (hipStream_t)stream, a,
+                         t->prep_ws);
+    else if (t->prep_a_lds)
       hipLaunchKernelGGL(prep_block_kernel<true>, dim3(grid), dim3(PREP_NT),
                          sizeof(double) * (size_t)t->N * t->N, (hipStream_t)stream, a, t->prep_ws);
     else

@@ -81,7 +81,8 @@
 // prepare (workgroup per goal); the plain kernels of gik_prep.hip.h are defined next to these
 #define GIK_KERNELS_PREP(X)                            \
   X(void prep_block_kernel<true>(PrepArgs, double *))  \
-  X(void prep_block_kernel<false>(PrepArgs, double *))
+  X(void prep_block_kernel<false>(PrepArgs, double *)) \
+  X(void prep_block_kernel<false, PREP_BIGN>(PrepArgs, double *))
 
 #define GIK_ALL_KERNELS(X)                                                                             \
   GIK_KERNELS_WAVE3(X) GIK_KERNELS_WAVE3_STRICT(X) GIK_KERNELS_ANCH(X) GIK_KERNELS_WAVE2(X) GIK_KERNELS_BLOCK(X) \

@@ -599,7 +599,7 @@ __device__ inline void jacobi_blk(double *A, double *V, int N, int sweeps, doubl
   double *cs_log = vlog;
   int *pq_log = reinterpret_cast<int *>(vlog + JLOG_ROUNDS * PREP_MAXN);
   double *rows = vlog + JLOG_ROUNDS * PREP_MAXN + JLOG_ROUNDS * (PREP_MAXN / 2) / 2;   // two rows per wavefront
-  const bool logged = V != nullptr && vlog != nullptr;
+  const bool logged = V != nullptr && vlog != nullptr && N <= PREP_MAXN;   // (the log's rows hold 2 x 64 columns)
   int nlog = 0;
   // quotient / remainder of the thread's first item and of the stride, for both item orders
   const int col_i0 = tid / np, col_m0 = tid - col_i0 * np, col_dq = PREP_NT / np, col_dr = PREP_NT - col_dq * np;
@@ -738,7 +738,7 @@ __device__ inline int count_eigs_above_blk(double *A, int N, double tau, double 
     const double alpha = x0 > 0.0 ? -sqrt(s_all) : sqrt(s_all);
     const double vj = mine ? (tid == 0 ? x - alpha : x) : 0.0;
     const double beta = 1.0 / (s_all - alpha * x0);
-    if (tid < PREP_MAXN) v[tid] = vj;
+    if (tid < N) v[tid] = vj;
     __syncthreads();
     double pj = 0.0;
     if (mine)
@@ -746,7 +746,7 @@ __device__ inline int count_eigs_above_blk(double *A, int N, double tau, double 
     pj *= beta;
     const double Kc = 0.5 * beta * prep_block_sum(vj * pj, red, tid);
     const double wj = pj - Kc * vj;
-    if (tid < PREP_MAXN) w[tid] = mine ? wj : 0.0;
+    if (tid < N) w[tid] = mine ? wj : 0.0;
     __syncthreads();
     if (mine) {
       for (int i = 0; i < m; ++i) {
@@ -786,7 +786,7 @@ constexpr int PREP_COMPRESS_MIN_N = 48;
 constexpr int PREP_RMAX = 64;
 
 // A: N x N (row stride N; LDS or global), destroyed.  Bc: global copy of B (out).  Qt: global, row m =
-// basis vector m (row stride N).  nrm, qv, cj: LDS [PREP_MAXN] each.
+// basis vector m (row stride N).  nrm, qv, cj: LDS, N doubles each (the kernel's MAXN).
 __device__ inline int range_basis_blk(double *A, int N, double *Bc, double *Qt, double *nrm, double *qv, double *cj,
                                       double *red, int tid) {
   const int NN = N * N;
@@ -852,8 +852,8 @@ __device__ inline int range_basis_blk(double *A, int N, double *Bc, double *Qt, 
       Qt[r * N + tid] = qi;
     }
     __syncthreads();
-    {   // c_j = <q, A[:, j]>: four threads per column
-      const int j = tid >> 2, part = tid & 3;
+    for (int j0 = 0; j0 < N; j0 += PREP_NT / 4) {   // c_j = <q, A[:, j]>: four threads per column, 128 columns at a time
+      const int j = j0 + (tid >> 2), part = tid & 3;
       double c = 0.0;
       if (j < N)
         for (int i = part; i < N; i += 4) c = fma(qv[i], A[i * N + j], c);
@@ -923,18 +923,29 @@ __device__ inline void expand_from_basis_blk(double *A, double *V, int N, int r,
 // Gram matrix = Jacobi / Householder work matrix, then the scatter matrix) lives in the dynamic LDS
 // segment instead of the global slab -- the kernel is bound by the L2 traffic of the Jacobi rounds,
 // two thirds of which are the work matrix's (N <= 123: 8 N^2 bytes next to the 41 KB of static LDS)
-template <bool A_LDS>
+// MAXN: rows the small LDS arrays hold -- 128 (PREP_MAXN), or 256 (PREP_BIGN, round 6) for graphs of 129 .. 255 nodes
+// (UR10 + a scene of more than 112 spheres: N = 216 with table_environment(12, 14)), whose work matrix lives in the
+// slab (A_LDS = false) and which ALWAYS go through the range compression (their slab has a sixth matrix for the copy
+// of the Gram matrix the compression needs; with the work matrix in LDS that copy takes the work matrix's slot).
+// Such a graph has few nodes outside its rigid anchor clique -- the solve kernel that takes it asks for that -- so
+// the rank of its Gram matrix is small (27 at N = 216) and every Jacobi of the kernel runs on <= 64 rows; the paths
+// that would need more (a fallback to the full N x N decomposition, more than 128 MDS columns) exist in slow form
+// (rotations applied round by round) or are refused (K_out = -1, Y_init = NaN: the solve reports stop = 2).
+constexpr int PREP_BIGN = 256;
+template <bool A_LDS, int MAXN = PREP_MAXN>
 __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double *ws) {
+  static_assert(MAXN == PREP_MAXN || (MAXN == PREP_BIGN && !A_LDS), "");
+  constexpr int SLAB = MAXN > PREP_MAXN ? 6 : 5;      // N x N matrices per workgroup
   extern __shared__ __attribute__((aligned(16))) double sh_A[];
   __shared__ double gd[2 * PREP_MAXA + 16];     // (several end effectors: checked at attach)
-  __shared__ double cs[2 * (PREP_MAXN / 2)];
-  __shared__ double ev[PREP_MAXN], sg[PREP_MAXN], red[PREP_NT / 64];
-  __shared__ int pq[PREP_MAXN / 2], rk[PREP_MAXN], cinv[PREP_MAXN];
+  __shared__ double cs[2 * (MAXN / 2)];
+  __shared__ double ev[MAXN], sg[MAXN], red[PREP_NT / 64];
+  __shared__ int pq[MAXN / 2], rk[MAXN], cinv[MAXN];
   __shared__ double dl[PREP_PC * PREP_MAXN];    // edge differences of PREP_PC pairs; Jacobi rotation log
   static_assert(JLOG_DOUBLES <= PREP_PC * PREP_MAXN, "the rotation log shares the scatter phase's tile buffer");
   const PipeConst &pc = a.pc;
   const int N = pc.N, K = pc.K, NN = N * N, tid = threadIdx.x;
-  double *Ug = ws + (size_t)blockIdx.x * 5 * NN;
+  double *Ug = ws + (size_t)blockIdx.x * SLAB * NN;
   double *L = Ug + NN;                           // lower bounds
   double *Ag = L + NN;
   // the LDS buffer holds the upper bounds during bound smoothing (N Floyd-Warshall rounds over the
@@ -1045,11 +1056,12 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
     int nc = N;
     {
       int rnk = -1;
-      if (A_LDS && N >= PREP_COMPRESS_MIN_N && !a.no_compress) {
-        // (global buffers free at this point: the slab's copy of the upper bounds Ug -- they live in LDS --, the
-        // work-matrix slot A1, V and X; NOT the lower-bound table L, which stays for the next goal; graphs whose
-        // work matrix itself sits in the slab, N > 123, keep the full decomposition)
-        double *Bc = A1, *Qt = X, *Tt = V, *W = Ug;       // (V is written by expand_from_basis_blk, after Tt's last use)
+      if ((A_LDS || MAXN > PREP_MAXN) && N >= PREP_COMPRESS_MIN_N && (!a.no_compress || MAXN > PREP_MAXN)) {
+        // (global buffers free at this point: the slab's upper bounds Ug -- their last reader was D_rand --, the
+        // work-matrix slot A1 when the work matrix is in LDS, V and X; NOT the lower-bound table L, which stays for the
+        // next goal; graphs of 124 .. 128 nodes, whose work matrix sits in a five-matrix slab, keep the full
+        // decomposition; graphs beyond 128 nodes have a sixth matrix for the copy)
+        double *Bc = A_LDS ? A1 : Ug + 5 * NN, *Qt = X, *Tt = V, *W = Ug;   // (V is written by expand_from_basis_blk, after Tt's last use)
         rnk = range_basis_blk(A, N, Bc, Qt, ev, sg, cs, red, tid);
         if (rnk >= 0) {
           compress_to_basis_blk(A, N, rnk, Bc, Qt, Tt, W, tid);
@@ -1116,6 +1128,12 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       __syncthreads();
     }
     const int Kc = count_eigs_above_blk(A, N, 1e-8, ev, sg, red, tid);
+    if (MAXN > PREP_MAXN && Kc > PREP_MAXN) {      // (more MDS columns than the scatter phase stages: see the kernel's head)
+      if (a.K_out && tid == 0) a.K_out[b] = -1;
+      for (int t = tid; t < N * K; t += PREP_NT) a.Y_init[(size_t)b * N * K + t] = __builtin_nan("");
+      __syncthreads();
+      continue;
+    }
     if (a.K_out && tid == 0) a.K_out[b] = Kc;
     __syncthreads();
 #ifdef GIK_DEV

@@ -237,9 +237,9 @@ class BatchProblem:
         """Hand the goal-independent pre/post-processing data to the device handle."""
         g, T = self.graph, self.template
         n = self.robot.n
-        if len(self.anchor_nodes) > 256 or self.N > 128 or len(self.end_effectors) > 4 or \
+        if len(self.anchor_nodes) > 256 or self.N > (255 if self.dim == 3 else 128) or len(self.end_effectors) > 4 or \
                 (self.dim == 2 and self.multi_ee):
-            # beyond the device prepare / recover kernels (N <= 128, <= 4 end effectors, planar
+            # beyond the device prepare / recover kernels (N <= 128, 3-D graphs 255; <= 4 end effectors; planar
             # chains): host pre/post-processing around the device solve
             self.device_pipeline = False
             return

@@ -91,12 +91,28 @@ def test_full_size_c3_ur10_table(torch_cuda):
     # the recover kernel's pose error is the error of FK(q) (host FK of the device's angles)
     pos_h, rot_h = prob.pose_errors(r["q"][:256], Tg[:256])
     assert np.allclose(pos_h, r["pos"][:256], atol=1e-9) and np.allclose(rot_h, r["rot"][:256], atol=1e-7)
-    # oracle from the device's initial points, 8 goals (about 1 s each per thread)
-    D, _, _ = prob.assemble(Tg[:8])
-    o = co.rtr_solve_batch(r["Y0"][:8], D, prob.omega, prob.psi_L, prob.psi_U, True, fast=False)
-    assert np.mean((r["f"][:8] < 1e-9) == (o["f(x)"] < 1e-9)) >= 0.75
-    conv = (r["f"][:8] < 1e-9) & (o["f(x)"] < 1e-9)
-    assert 0.6 < np.median(r["iterations"][:8][conv]) / np.median(o["iterations"][conv]) < 1.6
+    # The TAIL on the scene itself (the batch time of this config IS its tail): the 64 longest goals of the run
+    # -- every one of the 23 that stop at maxiter among them -- and 64 random ones, solved by the oracle from the device's
+    # start points (1-25 s each per thread: ~2 min on the box).  Measured round 6 (tools/c3_tail.py): all 23 maxiter goals
+    # are maxiter goals of the oracle, none other; convergence class equal on 128 / 128; outer iterations of the goals
+    # that converge in both 1.003x (longest) / 0.997x (random); Hessian products +4.7 % / +3.5 % -- the closed form of the
+    # 106-anchor clique sums the same terms through 24 moments, and tCG's iteration count feels the different round-off
+    # (a graph without a clique on the same kernel: +1.1 %, test_effort_parity_kuka_tail[npt]).
+    its, hv = r["iterations"], r["inner_total"].astype(np.int64)
+    longest = np.argsort(-its, kind="stable")[:64]
+    rnd = np.random.RandomState(1).choice(np.setdiff1d(np.arange(B), longest), 64, replace=False)
+    idx = np.concatenate([longest, rnd])
+    D, _, _ = prob.assemble(Tg[idx])
+    o = co.rtr_solve_batch(r["Y0"][idx], D, prob.omega, prob.psi_L, prob.psi_U, True, fast=False)
+    oi, oh = o["iterations"], o["inner_total"].astype(np.int64)
+    mx, mxo = its[idx] >= 3000, oi >= 3000
+    assert (its >= 3000).sum() <= 64 and mxo.sum() >= 0.9 * mx.sum()        # the sample holds the whole maxiter tail
+    assert np.mean(mx == mxo) >= 0.95 and np.mean((r["f"][idx] < 1e-9) == (o["f(x)"] < 1e-9)) >= 0.95
+    assert np.percentile(its[idx], 90) <= 1.10 * np.percentile(oi, 90)
+    both = ~mx & ~mxo
+    assert 0.97 < its[idx][both].sum() / oi[both].sum() < 1.03, its[idx][both].sum() / oi[both].sum()
+    assert 0.9 < np.median(its[idx][64:]) / np.median(oi[64:]) < 1.1
+    assert 0.97 < hv[idx].sum() / oh.sum() < 1.06, hv[idx].sum() / oh.sum()
 
 
 def test_full_size_c4_kuka_share(torch_cuda):
@@ -114,12 +130,16 @@ def test_full_size_c4_kuka_share(torch_cuda):
     ok = (r["pos"] < 0.01) & (r["rot"] < 0.01)
     assert ok.mean() > 0.95 and np.median(r["pos"]) < 5e-4          # measured 0.981, 2.0e-4
     assert 0.04 < (r["stop"] == 1).mean() < 0.12                     # measured 0.081 (the reference: 2 of 8)
-    n = 64
+    # oracle sub-sample from the device's start points: 256 goals (round 6: the 0.6-1.6 / 0.8-1.25 bands of rounds 2-5
+    # dated from before the causes of the effort differences were known; ~3.5 % of KUKA goals change their maxiter class
+    # between any two correct renderings, in both directions: test_effort_parity_kuka_tail)
+    n = 256
     D, _, _ = prob.assemble(Tg[:n])
     o = co.rtr_solve_batch(r["Y0"][:n], D, prob.omega, prob.psi_L, prob.psi_U, True, fast=False)
-    assert np.mean((r["f"][:n] < 1e-9) == (o["f(x)"] < 1e-9)) > 0.9
-    assert 0.6 < np.median(r["iterations"][:n]) / np.median(o["iterations"]) < 1.6
-    assert 0.8 < r["inner_total"][:n].sum() / o["inner_total"].sum() < 1.25
+    assert np.mean((r["f"][:n] < 1e-9) == (o["f(x)"] < 1e-9)) >= 0.94
+    assert 0.9 < np.median(r["iterations"][:n]) / np.median(o["iterations"]) < 1.1
+    both = (r["iterations"][:n] < 3000) & (o["iterations"] < 3000)
+    assert 0.96 < r["inner_total"][:n][both].sum() / o["inner_total"][both].sum() < 1.06
 
 
 def test_full_size_c4_kuka_whole_batch(torch_cuda):
@@ -140,9 +160,10 @@ def test_full_size_c4_kuka_whole_batch(torch_cuda):
     idx = np.arange(0, B, 683)[:96]
     D, _, _ = prob.assemble(Tg[idx])
     o = co.rtr_solve_batch(r["Y0"][idx], D, prob.omega, prob.psi_L, prob.psi_U, True, fast=False)
-    assert np.mean((r["f"][idx] < 1e-9) == (o["f(x)"] < 1e-9)) > 0.9
-    assert 0.6 < np.median(r["iterations"][idx]) / np.median(o["iterations"]) < 1.6
-    assert 0.8 < r["inner_total"][idx].sum() / o["inner_total"].sum() < 1.25
+    assert np.mean((r["f"][idx] < 1e-9) == (o["f(x)"] < 1e-9)) >= 0.92
+    assert 0.85 < np.median(r["iterations"][idx]) / np.median(o["iterations"]) < 1.15
+    both = (r["iterations"][idx] < 3000) & (o["iterations"] < 3000)
+    assert 0.95 < r["inner_total"][idx][both].sum() / o["inner_total"][both].sum() < 1.07
     # the 8192-goal share of an 8-GPU run is rows 0..8191 of the same stream: same answers in either batch
     r8 = prob.template.ik(torch_cuda.from_numpy(Tg[:8192]).cuda())
     assert np.array_equal(r8["x"].cpu().numpy(), r["x"][:8192]) and np.array_equal(r8["q"].cpu().numpy(), r["q"][:8192])
