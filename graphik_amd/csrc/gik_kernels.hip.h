@@ -882,8 +882,8 @@ __global__ void __launch_bounds__(WAVE, 3) rtr_quad_kernel(SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   double2 *sh_P = reinterpret_cast<double2 *>(smem);
-  double2 *sh_W = sh_P + QUAD_SLOTS * QUAD_NODES;
-  double *sh_tg = reinterpret_cast<double *>(sh_W + QUAD_SLOTS * QUAD_NODES);
+  double2 *sh_W = sh_P + QUAD_ROWS;
+  double *sh_tg = reinterpret_cast<double *>(sh_W + QUAD_ROWS);
   int *sh_claim = reinterpret_cast<int *>(sh_tg + DEG * WAVE);
   Ctx cx;
   cx.init(lane, a.N, sh_P, sh_W, sh_tg, a.slot_meta);
@@ -1107,8 +1107,8 @@ __global__ void __launch_bounds__(WAVE) kat_quad_kernel(KatArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   double2 *sh_P = reinterpret_cast<double2 *>(smem);
-  double2 *sh_W = sh_P + QUAD_SLOTS * QUAD_NODES;
-  double *sh_tg = reinterpret_cast<double *>(sh_W + QUAD_SLOTS * QUAD_NODES);
+  double2 *sh_W = sh_P + QUAD_ROWS;
+  double *sh_tg = reinterpret_cast<double *>(sh_W + QUAD_ROWS);
   Ctx cx;
   cx.init(lane, a.N, sh_P, sh_W, sh_tg, a.slot_meta);
   const int b_raw = (int)blockIdx.x * QUAD_SLOTS + cx.slot, NK = a.N * 2;
