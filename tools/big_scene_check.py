@@ -1,7 +1,7 @@
 """A scene beyond 128 nodes (round 5): UR10 + table_environment(n_width=12, n_height=14) = 200 spheres, N = 216 --
 the reference takes any number of spheres (graph_base.py:182-211); until round 5 gik_template_create refused N > 128.
 Known answers of the four-wavefront node-per-lane kernel against the CPU oracle, trajectories of a few goals,
-a batch through solve_batch (host prepare / recover: the device pipeline stops at 128 nodes), throughput.
+a batch through solve_batch (since round 6 prepare / recover run on the device too: prep_block_kernel<false, 256>), throughput.
     python tools/big_scene_check.py [B]"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -53,7 +53,7 @@ q, Yb, info = solve_batch(graph, Tg, use_limits=True)
 dt = time.time() - t0
 Ts = robot.fk_batch(q)
 pos = np.linalg.norm(Ts[:, :3, 3] - Tg[:, :3, 3], axis=1)
-print("solve_batch %d goals: %.2f s wall (host prepare + device solve + host recover), success %.3f, median pos err %.2e, outer its median %d max %d"
+print("solve_batch %d goals: %.2f s wall (device prepare + solve + recover: gik_ik_batch), success %.3f, median pos err %.2e, outer its median %d max %d"
       % (B, dt, float(np.mean(pos < 0.01)), float(np.median(pos)), int(np.median(info["iterations"])), int(np.max(info["iterations"]))), flush=True)
 # device solve alone
 targets, Y0 = prob.prepare(Tg)
