@@ -119,8 +119,8 @@ typedef struct {
    *   GIK_HESS_COLUMN: rows of the 3 x 3 blocks 2 a y y^T + c I, cached per accepted point, times the neighbour's
    *     entries.  s is never formed: the Gauss-Newton part's round-off leaves range(J^T) and truncated CG needs 5-8 %
    *     more Hessian products than the reference's arithmetic (7-DOF end configurations 8.4e-3 rad from the reference,
-   *     2.8 x the reference pair's own spread).  Until round 5 the default; since round 6 NOT faster either (c2 34.6 k
-   *     against 35.0 k solves/s, c4 126 k against 130 k: DESIGN.md 4.1) -- kept as the form of the ConjugateGradient,
+   *     2.8 x the reference pair's own spread).  Until round 5 the default; since round 6 NOT faster either (c2 34.5 k
+   *     against 35.3 k solves/s, c4 125.6 k against 136.0 k: DESIGN.md 4.1, 6) -- kept as the form of the ConjugateGradient,
    *     theta != 1, anchored and planar wavefront kernels, and as an explicit choice for comparisons.
    *   GIK_HESS_AUTO (default): PER_EDGE where that kernel exists (3-D, TrustRegions, theta = 1, not anchored), else
    *     COLUMN.  An explicit GIK_HESS_PER_EDGE on a wavefront template without such a kernel is refused.
