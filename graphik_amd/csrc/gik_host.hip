@@ -975,7 +975,7 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   if (!t || !d) return fail("null argument");
   if (t->has_pipe) return fail("pipeline already attached");
   const int N = t->N, K = t->K, n = d->n_joints;
-  if (n < 1 || n > 31) return fail("n_joints out of range");
+  if (n < 1 || n > 125) return fail("n_joints out of range (1 .. 125)");
   if (d->n_anchor < 1 || d->n_anchor > PREP_MAXA) return fail("n_anchor must be in [1, 256]");
   if (N > PREP_BIGN - 1 || (N > PREP_MAXN && K != 3))
     return fail("the device pipeline handles graphs of up to 128 nodes (3-D: 255)");

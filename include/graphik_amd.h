@@ -270,7 +270,7 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
  * smoothing runs on (dgp.py:192-231), the omega pairs of linear_projection (dgp.py:174-183),
  * and the robot frames joint_variables needs (graph_revolute.py:251-318).                   */
 typedef struct {
-  int32_t n_joints;          /* n                                                          */
+  int32_t n_joints;          /* n (1 .. 125)                                               */
   const double *T0;          /* [(n+1)][(k+1)*(k+1)] frames at zero configuration, row-major */
   const int32_t *p_index;    /* [n+1] node index of p_i                                    */
   const int32_t *q_index;    /* [n+1] node index of q_i (k=3; ignored for k=2)             */

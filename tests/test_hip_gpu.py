@@ -1414,6 +1414,43 @@ def test_scene_with_200_spheres_beyond_128_nodes(torch_cuda):
     assert Y1.shape == (N, 3) and q1 is not None
 
 
+def test_chain_with_more_than_31_joints_through_the_device_pipeline(torch_cuda):
+    """gik_pipeline_attach took at most 31 joints until round 6 ("graphs the reference takes and the library
+    still refuses"); nothing in the prepare / recover kernels depends on the count.  A 40-joint 3-D chain (N = 84: the
+    node-per-lane solve kernel, the workgroup prepare kernel): the first outer iterations against the oracle decision
+    for decision, the device's joint angles and pose errors against the host recovery."""
+    from oracle import c_oracle as co
+    from graphik_amd.robots import RobotRevolute
+    from graphik_amd.graphs import ProblemGraphRevolute
+    from graphik_amd.solvers.riemannian_solver import BatchProblem, solve_batch
+    n = 40
+    rs = np.random.RandomState(0)
+    names = [f"p{i}" for i in range(1, n + 1)]
+    params = {"a": dict(zip(names, 0.1 + 0.2 * rs.rand(n))), "alpha": dict(zip(names, rs.choice([0, np.pi / 2, -np.pi / 2], n))),
+              "d": dict(zip(names, 0.1 * rs.rand(n))), "theta": dict(zip(names, np.zeros(n))), "modified_dh": False,
+              "num_joints": n}
+    robot = RobotRevolute(params)
+    graph = ProblemGraphRevolute(robot)
+    prob = BatchProblem(graph, use_limits=True)
+    assert graph.number_of_nodes() == 84 and prob.device_pipeline and prob.template.info["prepare_is_block"] == 1
+    B = 16
+    lb, ub = robot.limits_arrays()
+    Tg = robot.fk_batch(lb + (ub - lb) * rs.rand(B, n))
+    q, Y, info = solve_batch(graph, Tg)
+    assert np.all(info["stop"] != 2) and np.median(info["f(x)"]) < 1e-12
+    qh = np.asarray(prob.joint_variables(Y, Tg), dtype=float)
+    assert np.abs(np.mod(q - qh + np.pi, 2 * np.pi) - np.pi).max() < 1e-9
+    pos_h, rot_h = prob.pose_errors(q, Tg)
+    assert np.allclose(pos_h, info["pos_err"], atol=1e-9) and np.allclose(rot_h, info["rot_err"], atol=1e-7)
+    targets, Y0 = prob.prepare(Tg[:2])
+    D, _, _ = prob.assemble(Tg[:2])
+    r = prob.template.solve(Y0, targets, trace_cap=8)
+    for gi in range(2):
+        o = co.rtr_solve(np.asarray(Y0[gi]), D[gi], prob.omega, prob.psi_L, prob.psi_U, True, traj_cap=8)
+        assert np.array_equal(r["trace"]["numit"][gi].cpu().numpy()[:5], o["traj"]["numit"][:5])
+        assert (float(r["f"][gi]) < 1e-9) == (o["f(x)"] < 1e-9)
+
+
 def test_host_prepare_thread_pool_is_deterministic(torch_cuda):
     """Graphs beyond the device prepare kernel (N > 32) are pre-processed on a host thread pool:
     same values whatever the number of workers."""
