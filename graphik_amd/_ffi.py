@@ -84,6 +84,7 @@ class PipelineDesc(C.Structure):
         ("ee_goal_nodes", C.POINTER(C.c_int32)), ("ee_path", C.POINTER(C.c_int32)),
         ("n_goal_pairs", C.c_int32), ("reserved1", C.c_int32),
         ("goal_pair_a", C.POINTER(C.c_int32)), ("goal_pair_b", C.POINTER(C.c_int32)),
+        ("ee_goal_len", C.POINTER(C.c_double)),
     ]
 
 

@@ -1009,14 +1009,22 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   // end effectors: a chain is one path 0..n with goal nodes (goal_node0, goal_node1)
   const int n_ee = d->n_ee > 1 ? d->n_ee : 1;
   if (n_ee > PREP_MAX_EE) return fail("at most 4 end effectors");
-  if (n_ee > 1 && (K != 3 || !d->ee_goal_nodes || !d->ee_path || d->n_goal_pairs < 0 ||
+  if (n_ee > 1 && (!d->ee_goal_nodes || !d->ee_path || d->n_goal_pairs < 0 || (K == 2 && !d->ee_goal_len) ||
                    (d->n_goal_pairs > 0 && (!d->goal_pair_a || !d->goal_pair_b))))
-    return fail("several end effectors: k = 3 and ee_goal_nodes / ee_path / goal pairs required");
+    return fail("several end effectors: ee_goal_nodes / ee_path / goal pairs (k = 2: ee_goal_len) required");
   pc.n_ee = n_ee;
   pc.n_gg = n_ee > 1 ? d->n_goal_pairs : 0;
   std::vector<int> path((size_t)n_ee * (n + 1), -1);
+  bool inert_goal_slot = false;
+  for (int e = 0; e < PREP_MAX_EE; ++e) pc.ee_len[e] = (n_ee > 1 && K == 2 && e < n_ee) ? d->ee_goal_len[e] : d->goal_len;
   if (n_ee > 1) {
-    for (int g = 0; g < 2 * n_ee; ++g) pc.goal_node[g] = d->ee_goal_nodes[g];
+    for (int g = 0; g < 2 * n_ee; ++g) {
+      pc.goal_node[g] = d->ee_goal_nodes[g];
+      // -1: a planar tree's parent node that an earlier end effector's pose pins already (odd slots only)
+      if (pc.goal_node[g] < 0 && !(K == 2 && (g & 1))) return fail("bad ee_goal_nodes");
+      if (pc.goal_node[g] >= N) return fail("bad ee_goal_nodes");
+      inert_goal_slot = inert_goal_slot || pc.goal_node[g] < 0;
+    }
     for (size_t t = 0; t < path.size(); ++t) path[t] = d->ee_path[t];
     for (int e = 0; e < n_ee; ++e)
       for (int k = 0; k <= n; ++k) {
@@ -1085,7 +1093,7 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
       occ = 8;
     if (const char *e = getenv("GIK_PREP_WAVES_PER_CU")) occ = atoi(e);   // developer override
     t->prep_waves_per_cu = std::max(1, std::min(occ, 32));
-    if (N <= PREPQ_MAXN && !getenv("GIK_NO_PREP_QUAD")) {
+    if (N <= PREPQ_MAXN && !inert_goal_slot && !getenv("GIK_NO_PREP_QUAD")) {   // (inert slots: prep_wave_kernel skips them)
       t->prep_quad_smem = prep_quad_lds_bytes(N, 2 * n_ee * d->n_anchor + pc.n_gg);
       int qocc = 0;
       if (t->prep_quad_smem <= 40 * 1024 &&

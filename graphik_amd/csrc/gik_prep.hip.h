@@ -38,12 +38,14 @@ struct PipeConst {
   double goal_len;            // axis_length (k=3) / |p_{n-1} p_n| (k=2)
   double axis_length;
   int last_along_z;           // joint_variables: last link offset parallel to z (:314), bit e = end effector e
-  // several end effectors (k = 3 trees): goal poses are [B][n_ee][16]; goal node 2e / 2e+1 is
-  // (p, q) of end effector e.  Distances: gd[ai * 2 n_ee + g] anchor ai <-> goal node g, then the
+  // several end effectors (k = 3 trees; round 6: planar trees): goal poses are [B][n_ee][(K+1)^2]; goal node 2e / 2e+1 is
+  // (p, q) of end effector e (k = 2: the end effector and its parent).  Distances: gd[ai * 2 n_ee + g] anchor ai <-> goal node g, then the
   // n_gg goal-node pairs of DIFFERENT end effectors.  A chain has n_ee = 1, n_gg = 0 (the layout
   // and arithmetic of the single-end-effector kernels, bit for bit).
   int n_ee, n_gg;
-  int goal_node[2 * 4];       // graph node of goal node g
+  int goal_node[2 * 4];       // graph node of goal node g; -1: inert slot (k = 2 trees: a parent that an earlier
+                              // end effector's pose already pins -- graph_planar.py:136-145 through BatchProblem)
+  double ee_len[4];           // goal_len per end effector: axis_length (k = 3), |parent(e) e| (k = 2)
   const int *gg_a, *gg_b;     // [n_gg] goal-node slots of each pair
   const int *ee_path;         // [n_ee][n+1] joints from the root to end effector e, -1 padded
 };
@@ -56,7 +58,8 @@ __device__ inline void goal_node_pos(const PipeConst &pc, const double *Tg, int 
   const double *T = Tg + (size_t)(g >> 1) * D * D;
   for (int c = 0; c < K; ++c) {
     const double p = T[c * D + K];
-    w[c] = !(g & 1) ? p : ((K == 3) ? p + T[c * D + 2] * pc.goal_len : p - T[c * D + 0] * pc.goal_len);
+    const double len = pc.ee_len[g >> 1];
+    w[c] = !(g & 1) ? p : ((K == 3) ? p + T[c * D + 2] * len : p - T[c * D + 0] * len);
   }
 }
 
@@ -313,8 +316,10 @@ __global__ void __launch_bounds__(WAVE) prep_wave_kernel(PrepArgs a)
       int an, gn;
       const double d = goal_distance(pc, Tg, idx, an, gn);
       gd[idx] = d;
-      U[an * N + gn] = U[gn * N + an] = d;
-      L[an * N + gn] = L[gn * N + an] = d;
+      if (an >= 0 && gn >= 0) {      // (an inert goal slot pins nothing)
+        U[an * N + gn] = U[gn * N + an] = d;
+        L[an * N + gn] = L[gn * N + an] = d;
+      }
     }
     __builtin_amdgcn_wave_barrier();
     // per-term targets: squared goal distances for the goal edges, template constants otherwise
@@ -976,8 +981,10 @@ __global__ void __launch_bounds__(PREP_NT) prep_block_kernel(PrepArgs a, double 
       int an, gn;
       const double d = goal_distance(pc, Tg, idx, an, gn);
       gd[idx] = d;
-      U[an * N + gn] = U[gn * N + an] = d;
-      L[an * N + gn] = L[gn * N + an] = d;
+      if (an >= 0 && gn >= 0) {      // (an inert goal slot pins nothing)
+        U[an * N + gn] = U[gn * N + an] = d;
+        L[an * N + gn] = L[gn * N + an] = d;
+      }
     }
     __syncthreads();
     for (int t = tid; t < pc.T; t += PREP_NT) {
@@ -1381,7 +1388,7 @@ __global__ void __launch_bounds__(64) recover_kernel(RecoverArgs a)
     a.pos_err[b] = worst_p;     // (several end effectors: the worst of them)
     a.rot_err[b] = worst_r;
   } else {
-    const double *Tg = a.T_goal + (size_t)b * 9;
+    const double *Tg = a.T_goal + (size_t)b * 9 * pc.n_ee;
     // best_fit_transform of (p0, x, y) onto ((0,0), (-1,0), (0,1)) without reflection handling
     const double *A0 = P + pc.p_idx[0] * 2, *A1 = P + pc.x_idx * 2, *A2 = P + pc.y_idx * 2;
     const double ca[2] = {(A0[0] + A1[0] + A2[0]) / 3.0, (A0[1] + A1[1] + A2[1]) / 3.0};
@@ -1403,44 +1410,55 @@ __global__ void __launch_bounds__(64) recover_kernel(RecoverArgs a)
       const double ang = atan2(M10 + M01, M00 - M11);
       Rm[0] = cos(ang); Rm[1] = sin(ang); Rm[2] = sin(ang); Rm[3] = -cos(ang);
     }
-    double Rc[4] = {1, 0, 0, 1};
-    // FK of the recovered angles: T_i = T_{i-1} Rz(q_i) T0_{i-1}^-1 T0_i  (robot_planar.py:62-80)
-    double Fr[4] = {pc.T0[0], pc.T0[1], pc.T0[3], pc.T0[4]}, Ft[2] = {pc.T0[2], pc.T0[5]};
-    for (int i = 1; i <= n; ++i) {
-      const double *pu = P + pc.p_idx[i - 1] * 2, *pv = P + pc.p_idx[i] * 2;
-      const double d0 = pv[0] - pu[0], d1 = pv[1] - pu[1];
-      double f0 = Rm[0] * d0 + Rm[1] * d1, f1 = Rm[2] * d0 + Rm[3] * d1;
-      const double len = sqrt(f0 * f0 + f1 * f1);
-      f0 /= len;
-      f1 /= len;
-      const double s0 = Rc[0] * f0 + Rc[2] * f1, s1 = Rc[1] * f0 + Rc[3] * f1;  // R[u]^T f
-      const double th = atan2(s1, s0);
-      q[i - 1] = wrap_pi(th);
-      const double c = cos(th), s = sin(th);
-      const double n0 = Rc[0] * c + Rc[1] * s, n1 = -Rc[0] * s + Rc[1] * c;
-      const double n2 = Rc[2] * c + Rc[3] * s, n3 = -Rc[2] * s + Rc[3] * c;
-      Rc[0] = n0; Rc[1] = n1; Rc[2] = n2; Rc[3] = n3;
-      // T_rel = T0_{i-1}^-1 T0_i
-      const double *Ta = pc.T0 + (i - 1) * 9, *Tb = pc.T0 + i * 9;
-      const double a00 = Ta[0], a01 = Ta[1], a10 = Ta[3], a11 = Ta[4];
-      const double dxr = Tb[2] - Ta[2], dyr = Tb[5] - Ta[5];
-      const double rr[4] = {a00 * Tb[0] + a10 * Tb[3], a00 * Tb[1] + a10 * Tb[4],
-                            a01 * Tb[0] + a11 * Tb[3], a01 * Tb[1] + a11 * Tb[4]};
-      const double rt[2] = {a00 * dxr + a10 * dyr, a01 * dxr + a11 * dyr};
-      const double cq = cos(q[i - 1]), sq = sin(q[i - 1]);
-      // F <- F * Rz(q) * T_rel
-      const double g0 = Fr[0] * cq + Fr[1] * sq, g1 = -Fr[0] * sq + Fr[1] * cq;
-      const double g2 = Fr[2] * cq + Fr[3] * sq, g3 = -Fr[2] * sq + Fr[3] * cq;
-      Ft[0] += g0 * rt[0] + g1 * rt[1];
-      Ft[1] += g2 * rt[0] + g3 * rt[1];
-      Fr[0] = g0 * rr[0] + g1 * rr[2]; Fr[1] = g0 * rr[1] + g1 * rr[3];
-      Fr[2] = g2 * rr[0] + g3 * rr[2]; Fr[3] = g2 * rr[1] + g3 * rr[3];
+    // One walk from the root per end effector (a chain: the one path 0, 1, ..., n; planar trees, round 6: joints shared
+    // by several paths get the same angle from each -- graph_planar.py:147-176 walks the structure edges with R[u] per
+    // node, which along a path is the running product kept here).  FK of the recovered angles along the same path:
+    // T_i = T_{i-1} Rz(q_i) T0_{i-1}^-1 T0_i  (robot_planar.py:62-80); pose error: the worst end effector's.
+    double worst_p = 0.0, worst_r = 0.0;
+    for (int e = 0; e < pc.n_ee; ++e) {
+      const double *Te = Tg + (size_t)e * 9;
+      const int *path = pc.ee_path + e * (n + 1);
+      double Rc[4] = {1, 0, 0, 1};
+      double Fr[4] = {pc.T0[0], pc.T0[1], pc.T0[3], pc.T0[4]}, Ft[2] = {pc.T0[2], pc.T0[5]};
+      for (int k = 1; k <= n && path[k] >= 0; ++k) {
+        const int pred = path[k - 1], i = path[k];
+        const double *pu = P + pc.p_idx[pred] * 2, *pv = P + pc.p_idx[i] * 2;
+        const double d0 = pv[0] - pu[0], d1 = pv[1] - pu[1];
+        double f0 = Rm[0] * d0 + Rm[1] * d1, f1 = Rm[2] * d0 + Rm[3] * d1;
+        const double len = sqrt(f0 * f0 + f1 * f1);
+        f0 /= len;
+        f1 /= len;
+        const double s0 = Rc[0] * f0 + Rc[2] * f1, s1 = Rc[1] * f0 + Rc[3] * f1;  // R[u]^T f
+        const double th = atan2(s1, s0);
+        q[i - 1] = wrap_pi(th);
+        const double c = cos(th), s = sin(th);
+        const double n0 = Rc[0] * c + Rc[1] * s, n1 = -Rc[0] * s + Rc[1] * c;
+        const double n2 = Rc[2] * c + Rc[3] * s, n3 = -Rc[2] * s + Rc[3] * c;
+        Rc[0] = n0; Rc[1] = n1; Rc[2] = n2; Rc[3] = n3;
+        // T_rel = T0_pred^-1 T0_i
+        const double *Ta = pc.T0 + pred * 9, *Tb = pc.T0 + i * 9;
+        const double a00 = Ta[0], a01 = Ta[1], a10 = Ta[3], a11 = Ta[4];
+        const double dxr = Tb[2] - Ta[2], dyr = Tb[5] - Ta[5];
+        const double rr[4] = {a00 * Tb[0] + a10 * Tb[3], a00 * Tb[1] + a10 * Tb[4],
+                              a01 * Tb[0] + a11 * Tb[3], a01 * Tb[1] + a11 * Tb[4]};
+        const double rt[2] = {a00 * dxr + a10 * dyr, a01 * dxr + a11 * dyr};
+        const double cq = cos(q[i - 1]), sq = sin(q[i - 1]);
+        // F <- F * Rz(q) * T_rel
+        const double g0 = Fr[0] * cq + Fr[1] * sq, g1 = -Fr[0] * sq + Fr[1] * cq;
+        const double g2 = Fr[2] * cq + Fr[3] * sq, g3 = -Fr[2] * sq + Fr[3] * cq;
+        Ft[0] += g0 * rt[0] + g1 * rt[1];
+        Ft[1] += g2 * rt[0] + g3 * rt[1];
+        Fr[0] = g0 * rr[0] + g1 * rr[2]; Fr[1] = g0 * rr[1] + g1 * rr[3];
+        Fr[2] = g2 * rr[0] + g3 * rr[2]; Fr[3] = g2 * rr[1] + g3 * rr[3];
+      }
+      const double px = Ft[0], py = Ft[1], phi = atan2(Fr[2], Fr[0]);
+      const double dx = Te[2] - px, dy = Te[5] - py;
+      worst_p = fmax(worst_p, sqrt(dx * dx + dy * dy));
+      const double gphi = atan2(Te[3], Te[0]);
+      worst_r = fmax(worst_r, fabs(wrap_pi(gphi - phi)));
     }
-    const double px = Ft[0], py = Ft[1], phi = atan2(Fr[2], Fr[0]);
-    const double dx = Tg[2] - px, dy = Tg[5] - py;
-    a.pos_err[b] = sqrt(dx * dx + dy * dy);
-    const double gphi = atan2(Tg[3], Tg[0]);
-    a.rot_err[b] = fabs(wrap_pi(gphi - phi));
+    a.pos_err[b] = worst_p;
+    a.rot_err[b] = worst_r;
   }
 }
 #endif

@@ -262,7 +262,7 @@ class Template:
                         goal_len, base_lower, base_upper, anchor_index, anchor_pos, pair_i, pair_j,
                         term_src, term_static, last_link_along_z, jacobi_sweeps=0,
                         force_block_prepare=False, ee_goal_nodes=None, ee_path=None,
-                        goal_pair_a=(), goal_pair_b=()):
+                        goal_pair_a=(), goal_pair_b=(), ee_goal_len=None):
         """Give the handle what it needs to run from_pose + bound_smoothing +
         generate_initialization and joint_variables on the device (gik_pipeline_attach)."""
         keep = {}
@@ -304,6 +304,8 @@ class Template:
             d.n_goal_pairs = len(goal_pair_a)
             d.goal_pair_a = arr("ga", goal_pair_a, np.int32)
             d.goal_pair_b = arr("gb", goal_pair_b, np.int32)
+            if ee_goal_len is not None:                  # planar trees: the link parent(e) -> e per end effector
+                d.ee_goal_len = arr("el", ee_goal_len, np.float64)
         with torch.cuda.device(self.device):
             _ffi.check(self.lib.gik_pipeline_attach(self._h, C.byref(d)))
         self.n_joints = int(d.n_joints)

@@ -237,20 +237,35 @@ class BatchProblem:
         """Hand the goal-independent pre/post-processing data to the device handle."""
         g, T = self.graph, self.template
         n = self.robot.n
-        if len(self.anchor_nodes) > 256 or self.N > (255 if self.dim == 3 else 128) or len(self.end_effectors) > 4 or \
-                (self.dim == 2 and self.multi_ee):
-            # beyond the device prepare / recover kernels (N <= 128, 3-D graphs 255; <= 4 end effectors; planar
-            # chains): host pre/post-processing around the device solve
+        if len(self.anchor_nodes) > 256 or self.N > (255 if self.dim == 3 else 128) or len(self.end_effectors) > 4:
+            # beyond the device prepare / recover kernels (N <= 128, 3-D graphs 255; <= 4 end effectors):
+            # host pre/post-processing around the device solve
             self.device_pipeline = False
             return
+        # Device goal slots: two per end effector.  3-D: (p_e, q_e) = self.goal_nodes in order.  Planar (round 6: trees
+        # too): (the end effector, its parent); a parent that an earlier end effector's pose pins already gets an inert
+        # slot (-1) -- _pose_goal / BatchProblem keep the first definition.
+        if self.dim == 3:
+            dev_slots = list(self.goal_nodes)
+        else:
+            dev_slots, seen = [], set()
+            for e in self.end_effectors:
+                for name in (e, self.robot.parent[e]):
+                    node = g.index(name)
+                    dev_slots.append(node if node not in seen else -1)
+                    seen.add(node)
+            if any(dev_slots[2 * e] < 0 for e in range(len(self.end_effectors))):
+                self.device_pipeline = False       # (an end effector that is another one's parent: host path)
+                return
+        goal_slot = {node: sl for sl, node in enumerate(dev_slots) if node >= 0}
         goalset = set(self.goal_nodes)
         slot = {a: s for s, a in enumerate(self.anchor_nodes)}
-        G = len(self.goal_nodes)                     # 2 per end effector
+        G = len(dev_slots)                           # 2 per end effector
         # goal nodes of different end effectors that the goal graph ties by an equality edge
-        pairs = [(a, b) for a in range(G) for b in range(a + 1, G)
-                 if self.omega[self.goal_nodes[a], self.goal_nodes[b]] != 0 and
-                 np.isnan(g.dist[self.goal_nodes[a], self.goal_nodes[b]])]
-        pair_slot = {(self.goal_nodes[a], self.goal_nodes[b]): q for q, (a, b) in enumerate(pairs)}
+        live = sorted(goal_slot.values())
+        pairs = [(a, b) for ia, a in enumerate(live) for b in live[ia + 1:]
+                 if self.omega[dev_slots[a], dev_slots[b]] != 0 and np.isnan(g.dist[dev_slots[a], dev_slots[b]])]
+        pair_slot = {(dev_slots[a], dev_slots[b]): q for q, (a, b) in enumerate(pairs)}
         term_src = np.full(T.T, -1, dtype=np.int32)
         for t in range(T.T):
             i, j = int(T.term_i[t]), int(T.term_j[t])
@@ -258,7 +273,7 @@ class BatchProblem:
                 continue
             for a, gnode in ((i, j), (j, i)):
                 if gnode in goalset and a in slot:
-                    term_src[t] = slot[a] * G + self.goal_nodes.index(gnode)
+                    term_src[t] = slot[a] * G + goal_slot[gnode]
             if (i, j) in pair_slot or (j, i) in pair_slot:
                 term_src[t] = G * len(self.anchor_nodes) + pair_slot.get((i, j), pair_slot.get((j, i)))
         static = np.where(np.isnan(T.targets_static), self.base_D[T.term_i, T.term_j],
@@ -270,19 +285,21 @@ class BatchProblem:
                 lower[a, gnode] = lower[gnode, a] = np.nan
                 upper[a, gnode] = upper[gnode, a] = np.nan
         for a, b in pairs:
-            ga, gb = self.goal_nodes[a], self.goal_nodes[b]
+            ga, gb = dev_slots[a], dev_slots[b]
             lower[ga, gb] = lower[gb, ga] = upper[ga, gb] = upper[gb, ga] = np.nan
         I, J = np.nonzero(np.triu(self.omega))
         T0 = self.robot.T0_array()
-        ee_path = None
+        ee_path = np.full((len(self.end_effectors), n + 1), -1, dtype=np.int32)
+        for e, ee in enumerate(self.end_effectors):
+            path = [int(name[1:]) for name in self.robot.kinematic_map["p0"][ee]]
+            ee_path[e, :len(path)] = path
+        ee_len = None
         if self.dim == 3:
             p_idx = [g.index(f"p{i}") for i in range(n + 1)]
             q_idx = [g.index(f"q{i}") for i in range(n + 1)]
             along_z = 0                                   # one bit per end effector (:314)
-            ee_path = np.full((len(self.end_effectors), n + 1), -1, dtype=np.int32)
             for e, ee in enumerate(self.end_effectors):
                 path = [int(name[1:]) for name in self.robot.kinematic_map["p0"][ee]]
-                ee_path[e, :len(path)] = path
                 rel_last = np.linalg.inv(T0[path[-2]]) @ T0[path[-1]]
                 if np.linalg.norm(np.cross(rel_last[:3, 3], [0, 0, 1])) < 1e-10:
                     along_z |= 1 << e
@@ -292,6 +309,7 @@ class BatchProblem:
             q_idx = None
             along_z = 0
             goal_len = g.dist[self.goal_nodes[1], self.goal_nodes[0]]
+            ee_len = [g.dist[g.index(self.robot.parent[e]), g.index(e)] for e in self.end_effectors]
         T.attach_pipeline(T0=T0, p_index=p_idx, q_index=q_idx, x_index=g.index("x"),
                           y_index=g.index("y"), axis_length=g.axis_length,
                           goal_nodes=self.goal_nodes, goal_len=goal_len, base_lower=lower,
@@ -299,7 +317,7 @@ class BatchProblem:
                           anchor_pos=self.anchor_pos, pair_i=I, pair_j=J, term_src=term_src,
                           term_static=static, last_link_along_z=along_z,
                           force_block_prepare=self.force_block_prepare,
-                          ee_goal_nodes=self.goal_nodes if self.multi_ee else None, ee_path=ee_path,
+                          ee_goal_nodes=dev_slots if self.multi_ee else None, ee_path=ee_path, ee_goal_len=ee_len,
                           goal_pair_a=[a for a, _ in pairs], goal_pair_b=[b for _, b in pairs])
         self.device_pipeline = True
 

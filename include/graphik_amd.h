@@ -294,11 +294,14 @@ typedef struct {
   int32_t jacobi_sweeps;     /* 0 = default (10)                                           */
   int32_t force_block_prepare; /* 1: workgroup-per-goal prepare kernel even for small graphs
                                 (tests; GIK_PREP_FORCE_BLOCK is read once, at attach)         */
-  /* Robots with several end effectors (k = 3 trees, robot_base.py:29-41; at most 4): goal poses
-   * are [B][n_ee][16] in the order of `ee_goal_nodes`; n_ee <= 1 (or 0) is the chain above and
-   * the arrays below may be NULL.  last_link_along_z then holds one bit per end effector.     */
+  /* Robots with several end effectors (k = 3 trees, robot_base.py:29-41; round 6: planar trees,
+   * graph_planar.py:50-88; at most 4): goal poses are [B][n_ee][(k+1)^2] in the order of `ee_goal_nodes`;
+   * n_ee <= 1 (or 0) is the chain above and the arrays below may be NULL.  last_link_along_z then
+   * holds one bit per end effector.                                                             */
   int32_t n_ee;
-  const int32_t *ee_goal_nodes; /* [2 * n_ee] graph nodes (p_e, q_e) pinned by goal pose e      */
+  const int32_t *ee_goal_nodes; /* [2 * n_ee] graph nodes pinned by goal pose e: (p_e, q_e); k = 2: (the end effector,
+                                   its parent -- or -1 where an earlier end effector's pose pins that parent already:
+                                   graph_planar.py:136-145 keeps the first)                      */
   const int32_t *ee_path;       /* [n_ee][n + 1] joint numbers from the root to end effector e
                                    (path[0] = 0), -1 padded; a parent's number precedes its
                                    children's nowhere assumed                                   */
@@ -307,6 +310,7 @@ typedef struct {
   const int32_t *goal_pair_a, *goal_pair_b;  /* [n_goal_pairs] slots into ee_goal_nodes; term_src
                                    of such a term = 2 n_ee n_anchor + pair; of an anchor<->goal
                                    term = anchor_slot * 2 n_ee + goal slot                     */
+  const double *ee_goal_len;    /* [n_ee] k = 2 trees: length of the link parent(e) -> e (goal_len of a chain)      */
 } gik_pipeline_desc;
 
 int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *desc);

@@ -1840,13 +1840,17 @@ def test_anchored_near_lists_are_bit_identical(torch_cuda):
 
 @pytest.mark.parametrize("which", ["y5", "bin2"])
 def test_planar_tree_solve_batch(torch_cuda, which):
-    """Planar TREES (graph_planar.py:50-88; several end effectors, possibly sharing their parent):
-    host goal assembly + bound smoothing + initial point, device trust-region solve, host
-    joint_variables -- every end effector of the recovered configuration reaches its goal pose; and
+    """Planar TREES (graph_planar.py:50-88; several end effectors, possibly sharing their parent): since round 6 the
+    whole pipeline on the device (goal assembly + bound smoothing + initial point: prep_wave_kernel with an inert goal
+    slot for a shared parent, or prep_quad_kernel; joint_variables + FK per end effector: recover_kernel's path walk),
+    checked against the host layer -- every end effector of the recovered configuration reaches its goal pose; and
     the drop-in call with a {end effector: pose} dict."""
     from conftest import planar_tree
-    from graphik_amd.solvers.riemannian_solver import solve_batch, solve_with_riemannian
+    from graphik_amd.solvers.riemannian_solver import BatchProblem, solve_batch, solve_with_riemannian
+    from graphik_amd.utils import dgp
     robot, graph = planar_tree(which)
+    prob = BatchProblem(graph, use_limits=True)
+    assert prob.multi_ee and prob.device_pipeline
     rng = np.random.RandomState(6)
     lb, ub = robot.limits_arrays()
     B = 64
@@ -1858,6 +1862,21 @@ def test_planar_tree_solve_batch(torch_cuda, which):
     ok = (info["pos_err"] < 0.01) & (info["rot_err"] < 0.01)     # worst end effector per goal
     assert ok.mean() > 0.9, ok.mean()
     assert np.median(info["pos_err"]) < 1e-4
+    # device goal assembly + bound smoothing against the host's, the initial point up to its Gram matrix
+    dbg = prob.template.prepare_debug(Tg[:8])
+    D_h, lo, up = prob.assemble(Tg[:8])
+    lb_h, ub_h = dgp.floyd_warshall_bounds(lo, up)
+    assert np.abs(dbg["lb"].cpu().numpy() - lb_h).max() < 1e-12 and np.abs(dbg["ub"].cpu().numpy() - ub_h).max() < 1e-12
+    assert np.abs(dbg["targets"].cpu().numpy() - prob.targets_from_D(D_h)).max() < 1e-13
+    _, Y0_h = prob.prepare(Tg[:8])
+    Y0_d = dbg["Y_init"].cpu().numpy()
+    for gi in range(8):
+        assert np.abs(Y0_d[gi] @ Y0_d[gi].T - Y0_h[gi] @ Y0_h[gi].T).max() < 1e-8
+    # device joint recovery and pose errors (the worst end effector's) against the host's on the solved points
+    q_h = np.asarray(prob.joint_variables(Y, Tg), dtype=float)
+    assert np.abs(np.mod(q - q_h + np.pi, 2 * np.pi) - np.pi).max() < 1e-9
+    pos_h, rot_h = prob.pose_errors(q, Tg)
+    assert np.allclose(pos_h, info["pos_err"], atol=1e-9) and np.allclose(rot_h, info["rot_err"], atol=1e-7)
     T_goal = {ee: robot.pose(robot.array_to_q(Q[0]), ee) for ee in robot.end_effectors}
     q_sol, Y1 = solve_with_riemannian(graph, T_goal)
     for ee in robot.end_effectors:
