@@ -1008,7 +1008,7 @@ int gik_pipeline_attach(gik_template *t, const gik_pipeline_desc *d) {
   pc.goal1 = d->goal_node1;
   // end effectors: a chain is one path 0..n with goal nodes (goal_node0, goal_node1)
   const int n_ee = d->n_ee > 1 ? d->n_ee : 1;
-  if (n_ee > PREP_MAX_EE) return fail("at most 4 end effectors");
+  if (n_ee > PREP_MAX_EE) return fail("at most 8 end effectors");
   if (n_ee > 1 && (!d->ee_goal_nodes || !d->ee_path || d->n_goal_pairs < 0 || (K == 2 && !d->ee_goal_len) ||
                    (d->n_goal_pairs > 0 && (!d->goal_pair_a || !d->goal_pair_b))))
     return fail("several end effectors: ee_goal_nodes / ee_path / goal pairs (k = 2: ee_goal_len) required");

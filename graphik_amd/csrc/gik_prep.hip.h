@@ -43,13 +43,13 @@ struct PipeConst {
   // n_gg goal-node pairs of DIFFERENT end effectors.  A chain has n_ee = 1, n_gg = 0 (the layout
   // and arithmetic of the single-end-effector kernels, bit for bit).
   int n_ee, n_gg;
-  int goal_node[2 * 4];       // graph node of goal node g; -1: inert slot (k = 2 trees: a parent that an earlier
+  int goal_node[2 * 8];       // graph node of goal node g; -1: inert slot (k = 2 trees: a parent that an earlier
                               // end effector's pose already pins -- graph_planar.py:136-145 through BatchProblem)
-  double ee_len[4];           // goal_len per end effector: axis_length (k = 3), |parent(e) e| (k = 2)
+  double ee_len[8];           // goal_len per end effector: axis_length (k = 3), |parent(e) e| (k = 2)
   const int *gg_a, *gg_b;     // [n_gg] goal-node slots of each pair
   const int *ee_path;         // [n_ee][n+1] joints from the root to end effector e, -1 padded
 };
-constexpr int PREP_MAX_EE = 4;
+constexpr int PREP_MAX_EE = 8;      // (4 until round 6)
 
 // position of goal node g = 2 e + s of problem `Tg` ([n_ee][(K+1)^2]): p_e, or q_e = p_e + len z_e
 // (graph_revolute.py:243-249); k = 2: p_n, p_{n-1} = p_n - len x_n (graph_planar.py:136-145)

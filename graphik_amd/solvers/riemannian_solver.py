@@ -237,8 +237,8 @@ class BatchProblem:
         """Hand the goal-independent pre/post-processing data to the device handle."""
         g, T = self.graph, self.template
         n = self.robot.n
-        if len(self.anchor_nodes) > 256 or self.N > (255 if self.dim == 3 else 128) or len(self.end_effectors) > 4:
-            # beyond the device prepare / recover kernels (N <= 128, 3-D graphs 255; <= 4 end effectors):
+        if len(self.anchor_nodes) > 256 or self.N > (255 if self.dim == 3 else 128) or len(self.end_effectors) > 8:
+            # beyond the device prepare / recover kernels (N <= 128, 3-D graphs 255; <= 8 end effectors):
             # host pre/post-processing around the device solve
             self.device_pipeline = False
             return

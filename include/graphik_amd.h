@@ -295,7 +295,7 @@ typedef struct {
   int32_t force_block_prepare; /* 1: workgroup-per-goal prepare kernel even for small graphs
                                 (tests; GIK_PREP_FORCE_BLOCK is read once, at attach)         */
   /* Robots with several end effectors (k = 3 trees, robot_base.py:29-41; round 6: planar trees,
-   * graph_planar.py:50-88; at most 4): goal poses are [B][n_ee][(k+1)^2] in the order of `ee_goal_nodes`;
+   * graph_planar.py:50-88; at most 8): goal poses are [B][n_ee][(k+1)^2] in the order of `ee_goal_nodes`;
    * n_ee <= 1 (or 0) is the chain above and the arrays below may be NULL.  last_link_along_z then
    * holds one bit per end effector.                                                             */
   int32_t n_ee;

@@ -1896,6 +1896,41 @@ def test_planar_tree_solve_batch(torch_cuda, which):
         assert np.abs(np.mod(dq + np.pi, 2 * np.pi) - np.pi).max() < 1e-8
 
 
+def test_planar_tree_with_eight_end_effectors(torch_cuda):
+    """More than four end effectors (the device pipeline's limit until round 6): the balanced binary tree of height 3 --
+    14 joints, 8 end effectors, every pair of them sharing its parent -- through the device pipeline against the host
+    layer: bounds, targets, recovered angles, worst-end-effector pose errors."""
+    from graphik_amd.robots import RobotPlanar
+    from graphik_amd.graphs import ProblemGraphPlanar
+    from graphik_amd.utils import dgp, list_to_variable_dict
+    from graphik_amd.solvers.riemannian_solver import BatchProblem, solve_batch
+    n = 14
+    parents = {f"p{i}": [f"p{2 * i + 1}", f"p{2 * i + 2}"] for i in range(7)}
+    lim = np.full(n, np.pi / 2)
+    robot = RobotPlanar({"link_lengths": list_to_variable_dict(np.ones(n)), "num_joints": n, "parents": parents,
+                         "joint_limits_upper": list_to_variable_dict(lim), "joint_limits_lower": list_to_variable_dict(-lim)})
+    graph = ProblemGraphPlanar(robot)
+    assert len(robot.end_effectors) == 8
+    prob = BatchProblem(graph, use_limits=True)
+    assert prob.device_pipeline
+    rng = np.random.RandomState(2)
+    B = 32
+    Q = -lim + 2 * lim * rng.rand(B, n)
+    Tg = np.stack([[robot.pose(robot.array_to_q(q), ee).as_matrix() for ee in robot.end_effectors] for q in Q])
+    dbg = prob.template.prepare_debug(Tg[:4])
+    D_h, lo, up = prob.assemble(Tg[:4])
+    lb_h, ub_h = dgp.floyd_warshall_bounds(lo, up)
+    assert np.abs(dbg["lb"].cpu().numpy() - lb_h).max() < 1e-12 and np.abs(dbg["ub"].cpu().numpy() - ub_h).max() < 1e-12
+    assert np.abs(dbg["targets"].cpu().numpy() - prob.targets_from_D(D_h)).max() < 1e-13
+    q, Y, info = solve_batch(graph, Tg, use_limits=True)
+    assert np.all(info["stop"] != 2)
+    q_h = np.asarray(prob.joint_variables(Y, Tg), dtype=float)
+    assert np.abs(np.mod(q - q_h + np.pi, 2 * np.pi) - np.pi).max() < 1e-9
+    pos_h, rot_h = prob.pose_errors(q, Tg)
+    assert np.allclose(pos_h, info["pos_err"], atol=1e-9) and np.allclose(rot_h, info["rot_err"], atol=1e-7)
+    assert np.mean((info["pos_err"] < 0.01) & (info["rot_err"] < 0.01)) > 0.8
+
+
 def test_stream_capture_is_refused(torch_cuda):
     """A batch call on a capturing stream is refused with a message BEFORE anything that is illegal under capture
     happens (event queries / waits, workspace growth, the counter reset a replay would share: ADVICE r5), the capture
