@@ -80,23 +80,26 @@ struct Variant {
   solve_fn solve_strict, solve_strict_mig;   // hessian_form = GIK_HESS_PER_EDGE (k = 3, theta == 1), or null
   kat_fn kat_strict;
   lds_fn lds_strict;
+  solve_fn solve_strict_theta;               // ... any theta
 };
 #define GIK_VARIANT(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
-   lds_bytes_of<K, D>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
+   lds_bytes_of<K, D>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
 #define GIK_VARIANT_S(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
    lds_bytes_of<K, D>, nullptr, nullptr, nullptr, nullptr, rtr_wave_kernel<K, D, true, false, false, true>, \
-   rtr_wave_kernel<K, D, true, false, true, true>, kat_wave_kernel<K, D, false, true>, lds_bytes_strict<K, D>}
+   rtr_wave_kernel<K, D, true, false, true, true>, kat_wave_kernel<K, D, false, true>, lds_bytes_strict<K, D>, \
+   rtr_wave_kernel<K, D, false, false, false, true>}
 #define GIK_VARIANT_A(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
    lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, nullptr, \
-   nullptr, nullptr, nullptr, nullptr}
+   nullptr, nullptr, nullptr, nullptr, nullptr}
 #define GIK_VARIANT_AM(K, D) \
   {K, D, rtr_wave_kernel<K, D, true>, rtr_wave_kernel<K, D, false>, rcg_wave_kernel<K, D>, kat_wave_kernel<K, D>, \
    lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, \
    rtr_wave_kernel<K, D, true, false, true>, rtr_wave_kernel<K, D, true, false, false, true>, \
-   rtr_wave_kernel<K, D, true, false, true, true>, kat_wave_kernel<K, D, false, true>, lds_bytes_strict<K, D>}
+   rtr_wave_kernel<K, D, true, false, true, true>, kat_wave_kernel<K, D, false, true>, lds_bytes_strict<K, D>, \
+   rtr_wave_kernel<K, D, false, false, false, true>}
 // anchored templates only: the free-free formulation with more than 10 terms at a node runs on the
 // workgroup kernels (the 20-slot wavefront variant needed 796 B of scratch per lane: measured on the
 // two-end-effector tree of tests/golden/tree5.npz, 13 terms, 144 k against 382 k solves/s;
@@ -104,7 +107,7 @@ struct Variant {
 // workgroup kernels on the planar trees -- both stay)
 #define GIK_VARIANT_ANCH_ONLY(K, D) \
   {K, D, nullptr, nullptr, nullptr, nullptr, lds_bytes_of<K, D>, rtr_wave_kernel<K, D, true, true>, \
-   kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, nullptr, nullptr, nullptr, nullptr, nullptr}
+   kat_wave_kernel<K, D, true>, lds_bytes_anch<K, D>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
 static const Variant kVariants[] = {GIK_VARIANT_AM(3, 9), GIK_VARIANT_S(3, 10), GIK_VARIANT_ANCH_ONLY(3, 20),
                                     GIK_VARIANT(2, 6), GIK_VARIANT(2, 16), GIK_VARIANT(2, 31)};
 
@@ -711,13 +714,13 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   t->maxdeg = is_block ? SL : MD;
   t->variant = var;
   // The product form concerns the one-unknown-per-lane kernel only (every other kernel forms s = y . w per edge
-  // anyway).  There the per-edge form exists for k = 3, TrustRegions, theta = 1, free-free graphs and is what
-  // GIK_HESS_AUTO selects; an explicit GIK_HESS_PER_EDGE without such a kernel is refused.
+  // anyway).  There the per-edge form exists for k = 3, TrustRegions, free-free graphs and is what GIK_HESS_AUTO
+  // selects; an explicit GIK_HESS_PER_EDGE without such a kernel is refused.
   if (!is_block && d->k == 3 && d->hessian_form != GIK_HESS_COLUMN) {
-    const bool have = !ad && d->solver == GIK_SOLVER_TRUST_REGIONS && d->theta == 1.0 && var->solve_strict;
+    const bool have = !ad && d->solver == GIK_SOLVER_TRUST_REGIONS && var->solve_strict && var->solve_strict_theta;
     if (!have && d->hessian_form == GIK_HESS_PER_EDGE) {
       delete t;
-      return fail("hessian_form = GIK_HESS_PER_EDGE: wavefront kernel of 3-D free-free graphs, TrustRegions, theta = 1 only");
+      return fail("hessian_form = GIK_HESS_PER_EDGE: wavefront kernel of 3-D free-free graphs, TrustRegions only");
     }
     t->hess_per_edge = have;
   }
@@ -775,7 +778,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   const void *solve_kernel =
       is_block ? (cg ? (d->k == 3 ? (const void *)rcg_block_kernel<3> : (const void *)rcg_block_kernel<2>)
                      : (d->k == 3 ? (const void *)rtr_block_kernel<3> : (const void *)rtr_block_kernel<2>))
-               : (const void *)(ad ? var->solve_anch : (cg ? var->solve_cg : (t->hess_per_edge ? var->solve_strict : var->solve)));
+               : (const void *)(ad ? var->solve_anch : (cg ? var->solve_cg : (t->hess_per_edge ? (d->theta == 1.0 ? var->solve_strict : var->solve_strict_theta) : var->solve)));
   if (is_block && t->smem_bytes > 48 * 1024) {
     // more than the default dynamic-LDS allowance: opt in for exactly what this template needs
     const void *fns[2] = {solve_kernel, d->k == 3 ? (const void *)kat_block_kernel<3>
@@ -1596,7 +1599,8 @@ int gik_solve_batch(const gik_template *t, const double *d_Y_init, const double 
   } else {
     hipLaunchKernelGGL(t->anchored ? t->variant->solve_anch
                        : cg        ? t->variant->solve_cg
-                       : t->hess_per_edge ? (mig ? t->variant->solve_strict_mig : t->variant->solve_strict)
+                       : t->hess_per_edge ? (t->p.theta != 1.0 ? t->variant->solve_strict_theta
+                                             : (mig ? t->variant->solve_strict_mig : t->variant->solve_strict))
                        : mig       ? t->variant->solve_mig
                                    : (t->p.theta == 1.0 ? t->variant->solve : t->variant->solve_theta),
                        dim3(grid), dim3(WAVE), t->smem_bytes, (hipStream_t)stream, a);

@@ -25,9 +25,11 @@
 #define GIK_KERNELS_WAVE3_STRICT(X)                                  \
   X(void rtr_wave_kernel<3, 9, true, false, false, true>(SolveArgs)) \
   X(void rtr_wave_kernel<3, 9, true, false, true, true>(SolveArgs))  \
+  X(void rtr_wave_kernel<3, 9, false, false, false, true>(SolveArgs)) \
   X(void kat_wave_kernel<3, 9, false, true>(KatArgs))                \
   X(void rtr_wave_kernel<3, 10, true, false, false, true>(SolveArgs)) \
   X(void rtr_wave_kernel<3, 10, true, false, true, true>(SolveArgs)) \
+  X(void rtr_wave_kernel<3, 10, false, false, false, true>(SolveArgs)) \
   X(void kat_wave_kernel<3, 10, false, true>(KatArgs))
 // ... fixed-anchor formulation
 #define GIK_KERNELS_ANCH(X)                             \

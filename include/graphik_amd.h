@@ -112,7 +112,7 @@ typedef struct {
    *   GIK_HESS_PER_EDGE: the reference's arithmetic -- per edge  s = y . (W_i - W_j),  t = 2 s a y + c w,  +t to one end
    *     and -t to the other (costs.py:186-203), the form every other kernel of the library uses.  The three lanes of a
    *     node split its term list, each evaluates its terms completely from whole rows and the three partial vectors are
-   *     added (gik_wave_strict.hip.h).  Exists for TrustRegions, theta = 1, free-free (not anchored) graphs.
+   *     added (gik_wave_strict.hip.h).  Exists for TrustRegions (any theta), free-free (not anchored) graphs.
    *     Against the CPU oracle from the same start points (8192 random KUKA goals): Hessian products +1.7 %, share of
    *     goals at maxiter 668 / 677, p90 of the outer iterations 0.99 x; 7-DOF end configurations 2.9e-3 rad from the
    *     reference in the median (the reference's own two code paths: 3.0e-3).
@@ -120,9 +120,9 @@ typedef struct {
    *     entries.  s is never formed: the Gauss-Newton part's round-off leaves range(J^T) and truncated CG needs 5-8 %
    *     more Hessian products than the reference's arithmetic (7-DOF end configurations 8.4e-3 rad from the reference,
    *     2.8 x the reference pair's own spread).  Until round 5 the default; since round 6 NOT faster either (c2 34.5 k
-   *     against 35.3 k solves/s, c4 125.6 k against 136.0 k: DESIGN.md 4.1, 6) -- kept as the form of the ConjugateGradient,
-   *     theta != 1, anchored and planar wavefront kernels, and as an explicit choice for comparisons.
-   *   GIK_HESS_AUTO (default): PER_EDGE where that kernel exists (3-D, TrustRegions, theta = 1, not anchored), else
+   *     against 35.3 k solves/s, c4 125.6 k against 136.0 k: DESIGN.md 4.1, 6) -- kept as the form of the ConjugateGradient
+   *     (which takes no Hessian products), anchored and planar wavefront kernels, and as an explicit choice for comparisons.
+   *   GIK_HESS_AUTO (default): PER_EDGE where that kernel exists (3-D, TrustRegions, not anchored), else
    *     COLUMN.  An explicit GIK_HESS_PER_EDGE on a wavefront template without such a kernel is refused.
    * Graphs on the workgroup / node-per-lane kernels form s per edge whatever this field says (gik_template_info
    * reports GIK_HESS_PER_EDGE for them).                                                                          */

@@ -339,6 +339,83 @@ def test_gradient_roundoff_is_horizontal(torch_cuda, name):
         assert np.abs(G[b].sum(axis=0)).max() < 1e-12 * nrm   # translation-free as well
 
 
+@pytest.mark.parametrize("form", ["auto", "column"])
+def test_ten_terms_per_node_variant(torch_cuda, form):
+    """rtr_wave_kernel<3, 10, ...>: every packaged arm has at most nine terms per node, so the ten-slot variants (four
+    owned slots per lane in the per-edge context, one of them padding on most lanes) only run on graphs like this one --
+    UR10 + ONE spherical obstacle (N = 17: the obstacle ties to the four base anchors and the two goal nodes).  Known
+    answers against the oracle at 1e-12, the first outer iterations decision for decision, convergence class."""
+    from oracle import c_oracle as co
+    from graphik_amd.solvers.riemannian_solver import BatchProblem
+    from graphik_amd.utils.roboturdf import load_ur10
+    robot, graph = load_ur10()
+    graph.add_spherical_obstacle("o0", np.array([0.6, 0.1, 0.4]), 0.15)
+    prob = BatchProblem(graph, use_limits=True, params={"hessian_form": form})
+    T = prob.template
+    assert T.info["is_block"] == 0 and T.info["max_terms_per_node"] == 10 and T.info["hessian_form"] == int(form == "auto")
+    rs = np.random.RandomState(11)
+    B = 24
+    lb, ub = robot.limits_arrays()
+    Tg = robot.fk_batch(lb + (ub - lb) * rs.rand(B, robot.n))
+    targets, Y0 = prob.prepare(Tg)
+    D, _, _ = prob.assemble(Tg)
+    om, pL, pU = prob.omega, prob.psi_L, prob.psi_U
+    inds = co.limit_inds(om, pL, pU)
+    N = prob.N
+    for scale in (1.0, 1e-3):
+        Y = np.asarray(Y0[:4]) + scale * rs.randn(4, N, 3)
+        W = rs.randn(4, N, 3)
+        c, g, h = (T.cost(Y, targets[:4]).cpu().numpy(), T.grad(Y, targets[:4]).cpu().numpy(),
+                   T.hess(Y, W, targets[:4]).cpu().numpy())
+        for m in range(4):
+            assert abs(c[m] - co.lcost(Y[m], D[m], om, pL, pU, inds)) <= 1e-12 * abs(c[m])
+            assert rel_err(g[m], co.lgrad(Y[m], D[m], om, pL, pU, inds)) < 1e-12
+            assert rel_err(h[m], co.lhess(Y[m], W[m], D[m], om, pL, pU, inds)) < 1e-12
+    r = T.solve(Y0, targets, trace_cap=8)
+    q = prob.joint_variables(r["x"].cpu().numpy(), Tg)
+    pos, rot = prob.pose_errors(q, Tg)
+    same = 0
+    for gi in range(B):
+        o = co.rtr_solve(np.asarray(Y0[gi]), D[gi], om, pL, pU, True, traj_cap=8)
+        m = min(5, int(r["iterations"][gi]), o["iterations"])
+        assert np.array_equal(r["trace"]["numit"][gi].cpu().numpy()[:m], o["traj"]["numit"][:m]), gi
+        same += (float(r["f"][gi]) < 1e-9) == (o["f(x)"] < 1e-9)
+    assert same >= B - 1 and np.mean((pos < 0.01) & (rot < 0.01)) > 0.8
+
+
+@pytest.mark.parametrize("path", ["wave", "wave_column", "block"])
+@pytest.mark.parametrize("theta,kappa", [(0.5, 0.1), (2.0, 0.5)])
+def test_theta_and_kappa_against_the_oracle(torch_cuda, path, theta, kappa):
+    """The tCG stopping rule |r| <= |r0| min(|r0|^theta, kappa) (trust_region.py:572; the reference passes theta = 1,
+    kappa = 0.1) with other parameters: the kernels compiled for any theta (pow() in the per-solve setup; per-edge and
+    column-form wavefront kernels, the workgroup kernel) against the oracle with the same parameters -- the first outer
+    iterations decision for decision, the convergence class, the outer iteration counts in distribution."""
+    from oracle import c_oracle as co
+    from graphik_amd.engine import Template
+    d = load_golden("lwa4d")
+    T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=3, use_limits=True,
+                               params=dict(_PATH_PARAMS[path], theta=theta, kappa=kappa))
+    assert T.info["hessian_form"] == int(path != "wave_column") and T.info["node_per_lane"] == 0
+    r = T.solve(d["Y_init"], T.targets_from_D(d["D_goal"]), trace_cap=16)
+    its = r["iterations"].cpu().numpy()
+    f = r["f"].cpu().numpy()
+    its_o = []
+    for g in range(len(d["seed"])):
+        o = co.rtr_solve(d["Y_init"][g], d["D_goal"][g], d["omega"], d["psi_L"], d["psi_U"], True, traj_cap=16,
+                         theta=theta, kappa=kappa)
+        its_o.append(o["iterations"])
+        m = min(5, int(its[g]), o["iterations"])
+        assert np.array_equal(r["trace"]["numit"][g].cpu().numpy()[:m], o["traj"]["numit"][:m]), (g, theta, kappa)
+        assert np.array_equal(r["trace"]["stop"][g].cpu().numpy()[:m], o["traj"]["stop"][:m]), (g, theta, kappa)
+        assert (f[g] < 1e-9) == (o["f(x)"] < 1e-9)
+    assert 0.8 < np.median(its) / np.median(its_o) < 1.25
+    # and the parameters do something: the default's inner iteration counts differ (late in a solve for theta < 1: the
+    # superlinear target only binds once |r0| is small)
+    r1 = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=3, use_limits=True,
+                                params=_PATH_PARAMS[path]).solve(d["Y_init"], T.targets_from_D(d["D_goal"]), trace_cap=16)
+    assert not np.array_equal(r1["inner_total"].cpu().numpy(), r["inner_total"].cpu().numpy())
+
+
 @pytest.mark.parametrize("path", ["wave", "wave_column", "block", "npt"])
 def test_effort_parity_ur10(torch_cuda, path):
     """Same work as the reference's algorithm, not only the same answers: on random UR10 goals no
@@ -1997,12 +2074,13 @@ def test_c_abi_error_behaviour(torch_cuda):
     refused(L.gik_template_create(C.byref(desc(N=256)), C.byref(h)), "N must be")      # (round 5: up to 255)
     refused(L.gik_template_create(C.byref(desc(N=129, k=2)), C.byref(h)), "128 nodes")  # beyond 128: 3-D TrustRegions only
     refused(L.gik_template_create(C.byref(desc(hessian_form=3)), C.byref(h)), "hessian_form")
-    # an explicit per-edge product where no such kernel exists (ConjugateGradient, theta != 1) is refused, not ignored ...
+    # an explicit per-edge product where no such kernel exists (ConjugateGradient: it takes no Hessian products) is refused,
+    # not ignored ...
     refused(L.gik_template_create(C.byref(desc(hessian_form=_ffi.HESS_PER_EDGE, solver=_ffi.SOLVER_CONJUGATE_GRADIENT)), C.byref(h)), "GIK_HESS_PER_EDGE")
-    refused(L.gik_template_create(C.byref(desc(hessian_form=_ffi.HESS_PER_EDGE, theta=0.5)), C.byref(h)), "GIK_HESS_PER_EDGE")
     # ... while the default (GIK_HESS_AUTO) resolves to what the template's kernel does, and says so
     info = _ffi.TemplateInfo()
-    for kw, form in (({}, _ffi.HESS_PER_EDGE), ({"theta": 0.5}, _ffi.HESS_COLUMN), ({"solver": _ffi.SOLVER_CONJUGATE_GRADIENT}, _ffi.HESS_COLUMN),
+    for kw, form in (({}, _ffi.HESS_PER_EDGE), ({"theta": 0.5}, _ffi.HESS_PER_EDGE), ({"theta": 0.5, "hessian_form": _ffi.HESS_COLUMN}, _ffi.HESS_COLUMN),
+                     ({"solver": _ffi.SOLVER_CONJUGATE_GRADIENT}, _ffi.HESS_COLUMN),
                      ({"hessian_form": _ffi.HESS_COLUMN}, _ffi.HESS_COLUMN), ({"force_block_path": 1}, _ffi.HESS_PER_EDGE)):
         assert L.gik_template_create(C.byref(desc(**kw)), C.byref(h)) == 0, L.gik_last_error()
         assert L.gik_template_get_info(h, C.byref(info)) == 0 and info.hessian_form == form, (kw, info.hessian_form)
