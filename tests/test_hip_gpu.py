@@ -339,6 +339,42 @@ def test_gradient_roundoff_is_horizontal(torch_cuda, name):
         assert np.abs(G[b].sum(axis=0)).max() < 1e-12 * nrm   # translation-free as well
 
 
+_PARAM_SETS = {"maxinner5": {"maxinner": 5}, "mininner4": {"mininner": 4}, "rho": {"rho_prime": 0.2, "rho_regularization": 10.0},
+               "maxiter25": {"maxiter": 25}, "maxinner1": {"maxinner": 1}}
+
+
+@pytest.mark.parametrize("pset", sorted(_PARAM_SETS))
+@pytest.mark.parametrize("path", ["wave", "wave_column", "block", "npt", "planar_wave", "planar_quad"])
+def test_solver_parameters_against_the_oracle(torch_cuda, path, pset):
+    """The trust-region parameters of the descriptor (trust_region.py:85-121: maxinner, mininner, rho_prime,
+    rho_regularization, maxiter) away from the reference's defaults, on every solve kernel, against the oracle with the
+    same parameters: the cold paths of the single-reduction tCG loop -- inner iterations exhausted with the model test
+    pending (maxinner = 5, 1), the residual test held back (mininner = 4) -- and the acceptance rule.  First outer
+    iterations decision for decision (inner iteration counts, stopping reasons, acceptance), iteration counts equal where
+    maxiter cuts every solve."""
+    from oracle import c_oracle as co
+    from graphik_amd.engine import Template
+    planar = path.startswith("planar")
+    d = load_golden("planar10_limits_halfpi" if planar else "lwa4d")
+    kw = _PARAM_SETS[pset]
+    params = dict({"planar_wave": {"debug_flags": 8192}, "planar_quad": {"debug_flags": 16384}}.get(path) or _PATH_PARAMS[path], **kw)
+    use_lim = bool(int(d["use_limits"]))
+    T = Template.from_matrices(d["omega"], d["psi_L"], d["psi_U"], k=int(d["dim"]), use_limits=use_lim, params=params)
+    r = T.solve(d["Y_init"], T.targets_from_D(d["D_goal"]), trace_cap=12)
+    its = r["iterations"].cpu().numpy()
+    for g in range(len(d["seed"])):
+        o = co.rtr_solve(d["Y_init"][g], d["D_goal"][g], d["omega"], d["psi_L"], d["psi_U"], use_lim, traj_cap=12, **kw)
+        # (planar solves end at the round-off floor, where the last two iterations' stopping reasons are noise: the
+        #  planar trajectory tests compare up to the last two as well)
+        m = min(12, int(its[g]) - 2, o["iterations"] - 2) if planar else min(5, int(its[g]), o["iterations"])
+        for key in ("numit", "stop", "accept"):
+            assert np.array_equal(r["trace"][key][g].cpu().numpy()[:m], o["traj"][key][:m]), (g, key)
+        if "maxiter" in kw:
+            assert int(its[g]) == o["iterations"] or min(int(its[g]), o["iterations"]) < kw["maxiter"]
+        if "maxinner" in kw:
+            assert r["trace"]["numit"][g].cpu().numpy()[:m].max() <= kw["maxinner"] - 1
+
+
 @pytest.mark.parametrize("form", ["auto", "column"])
 def test_ten_terms_per_node_variant(torch_cuda, form):
     """rtr_wave_kernel<3, 10, ...>: every packaged arm has at most nine terms per node, so the ten-slot variants (four
