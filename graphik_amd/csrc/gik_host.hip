@@ -778,7 +778,7 @@ static int create_impl(const gik_template_desc *d, const gik_anchored_desc *ad, 
   const void *solve_kernel =
       is_block ? (cg ? (d->k == 3 ? (const void *)rcg_block_kernel<3> : (const void *)rcg_block_kernel<2>)
                      : (d->k == 3 ? (const void *)rtr_block_kernel<3> : (const void *)rtr_block_kernel<2>))
-               : (const void *)(ad ? var->solve_anch : (cg ? var->solve_cg : (t->hess_per_edge ? (d->theta == 1.0 ? var->solve_strict : var->solve_strict_theta) : var->solve)));
+               : (const void *)(ad ? var->solve_anch : (cg ? var->solve_cg : (t->hess_per_edge ? (d->theta == 1.0 ? (var->solve_strict_mig ? var->solve_strict_mig : var->solve_strict) : var->solve_strict_theta) : var->solve)));      // (occupancy: of the build large batches run -- the small-batch build trades registers for latency, gik_rtr.hip.h SPLIT)
   if (is_block && t->smem_bytes > 48 * 1024) {
     // more than the default dynamic-LDS allowance: opt in for exactly what this template needs
     const void *fns[2] = {solve_kernel, d->k == 3 ? (const void *)kat_block_kernel<3>

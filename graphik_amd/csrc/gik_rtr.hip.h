@@ -15,6 +15,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "gik_wave.hip.h"
 
 namespace gik {
@@ -130,6 +132,12 @@ __device__ inline bool mig_anyone_waiting(const Ctx &cx, const MigCtl &m) {
   return __builtin_amdgcn_readfirstlane(w) != 0;
 }
 
+// contexts whose Hessian product comes in two halves (ehess_begin / ehess_end: WaveCtxStrict)
+template <typename Ctx, typename = void>
+struct split_ehess : std::false_type {};
+template <typename Ctx>
+struct split_ehess<Ctx, std::enable_if_t<Ctx::SPLIT_EHESS>> : std::true_type {};
+
 // THETA_ONE: compiled for the reference default theta = 1 (trust_region.py:92), where
 // norm_r0 ** theta needs no pow().  The generic build evaluates pow() when theta != 1; inlined, its
 // polynomial constants are hoisted to the per-problem setup and spilled to scratch by every problem
@@ -143,6 +151,11 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
                                      int dbg, double *dbg_buf, int b, double &x, RtrOut &out,
                                      const RtrResume &rs, int slice_its, const MigCtl *mig = nullptr) {
   static_assert(!MIG || SLICE, "tail spreading needs the resume / pause hooks");
+  // The two-halves product (the next product's LDS round trip behind this step's updates) costs 22 VGPRs -- the gathered
+  // rows live across the loop's back edge: 153 -> 175 -- which a lone wavefront has and three per SIMD do not.  The
+  // MIG build is the one large batches run (two or three waves per SIMD, bound by the vector ALU, not by latency): it
+  // keeps the one-piece product.  Same values either way.
+  constexpr bool SPLIT = split_ehess<Ctx>::value && !MIG;
   const double Delta_bar = 10.0 + K;  // typicaldist (fixed_rank_psd_sym.py:71-73)
   const bool lead = cx.lead();
     double Delta = (SLICE && rs.resumed) ? rs.Delta : Delta_bar / 8.0;   // trust_region.py:134-135,164
@@ -296,7 +309,9 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
         // Returns true when tCG ends (result in eta_l / Heta_l, or `bad`).
         auto step = [&](const double ec, const double hc, const double pc, double &en, double &hn,
                         double &pn) __attribute__((always_inline)) -> bool {
-          const double H = cx.ehess(delta);        // :497
+          double H;                                // :497
+          if constexpr (SPLIT) H = cx.ehess_end();     // (its gathers were issued at the end of the last step)
+          else H = cx.ehess(delta);
           double v[8] = {cx.Q[0] * H, cx.Q[1] * H, cx.Q[2] * H,      delta * H,
                          w * H,       H * H,       ec * fma(0.5, hc, g), r * r};
           cx.template sum_n<8>(v);
@@ -424,16 +439,33 @@ __device__ inline void rtr_solve_one(Ctx &cx, const Params &p, const gik_trace &
           ++j;
           pn = e_Pe_new;                                    // :537
           model_prev = model_value;
-          en = fma(alpha, delta, ec);                       // :538, :556-558 (over the previous eta)
-          hn = fma(alpha, Hdelta, hc);                      // :542
-          r = fma(alpha, Hdelta, r);                        // :561
-          w = fma(-alpha, Hdelta, w);
-          delta = fma(beta, delta, w);                      // :593
+          if constexpr (SPLIT) {
+            // the next direction first, published and its gathers issued at once: the LDS round trip then runs behind
+            // the rest of this step's updates instead of in front of the next product (same values, another order)
+            en = fma(alpha, delta, ec);                     // :538 (reads the old delta)
+            w = fma(-alpha, Hdelta, w);
+            delta = fma(beta, delta, w);                    // :593
+            cx.ehess_begin(delta);
+            __builtin_amdgcn_sched_barrier(0);
+            hn = fma(alpha, Hdelta, hc);                    // :542
+            r = fma(alpha, Hdelta, r);                      // :561
+            // (forming the next step's two H-free summands here as well was tried: four register moves more between the
+            //  role-swapped steps, and the gain of the split gone -- NOTEBOOK 11.9)
+          } else {
+            en = fma(alpha, delta, ec);                     // :538, :556-558 (over the previous eta)
+            hn = fma(alpha, Hdelta, hc);                    // :542
+            r = fma(alpha, Hdelta, r);                      // :561
+            w = fma(-alpha, Hdelta, w);
+            delta = fma(beta, delta, w);                    // :593
+          }
           e_Pd2 = beta * fma(alpha + alpha, d_Pd, e_Pd2);   // :596 (carried as 2 <eta, delta>)
           d_Pd = fma(beta * beta, d_Pd, new_r_r);           // :597
           return false;
         };
         j = 0;
+        if constexpr (SPLIT) {
+          if (p.maxinner > 0) cx.ehess_begin(delta);
+        }
         if (p.maxinner > 0)
           for (;;) {                               // :495
             if (step(ea, ha, pa, eb, hb, pb)) break;

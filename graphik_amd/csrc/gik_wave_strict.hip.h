@@ -114,22 +114,32 @@ struct WaveCtxStrict : WaveCtx<3, MAXDEG, false, true> {
   }
 
   // ehess(Y, W) (lhess, costs.py:175-207) at the last commit(): H_i = sum_j [ (2 a y . w)(2 a y) + 2 c w ], w = W_i - W_j
-  __device__ inline double ehess(double W) {
+  // In two halves, so that the tCG loop can put the LDS round trip of the NEXT product (one write, eight reads: ~100
+  // cycles in which a lone wavefront has nothing else in flight) behind the bookkeeping of the current step:
+  // ehess_begin publishes the direction and issues the gathers, ehess_end consumes them (rtr_solve_one, SPLIT_EHESS).
+  static constexpr bool SPLIT_EHESS = true;
+  Row<3> wn_, rw_[NSH];
+  __device__ inline void ehess_begin(double W) {
     this->put1(W);
-    const Row<3> wn = this->read_row(this->nat_off);
-    Row<3> rw[NSH];
+    wn_ = this->read_row(this->nat_off);
 #pragma unroll
-    for (int k = 0; k < NSH; ++k) rw[k] = this->read_row(natoff[k]);
+    for (int k = 0; k < NSH; ++k) rw_[k] = this->read_row(natoff[k]);
+  }
+  __device__ inline double ehess_end() {
     double p[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < NSH; ++k) {
-      const double u0 = wn.v[0] - rw[k].v[0], u1 = wn.v[1] - rw[k].v[1], u2 = wn.v[2] - rw[k].v[2];
+      const double u0 = wn_.v[0] - rw_[k].v[0], u1 = wn_.v[1] - rw_[k].v[1], u2 = wn_.v[2] - rw_[k].v[2];
       const double s = fma(ysn[k][2], u2, fma(ysn[k][1], u1, ysn[k][0] * u0));
       p[0] = fma(s, ysn[k][0], fma(cc[k], u0, p[0]));
       p[1] = fma(s, ysn[k][1], fma(cc[k], u1, p[1]));
       p[2] = fma(s, ysn[k][2], fma(cc[k], u2, p[2]));
     }
     return triple_sum(p);
+  }
+  __device__ inline double ehess(double W) {
+    ehess_begin(W);
+    return ehess_end();
   }
 
   __device__ inline double hess_proj_dot(double delta, const double (&s_dpk)[3], double &d_Hd, double (&hd_pk)[3]) {
